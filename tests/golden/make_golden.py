@@ -1,0 +1,472 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference (read-only at /root/reference).
+
+Run in the build container only:  python tests/golden/make_golden.py
+The GPU box never sees /root/reference; it only sees the .npz files this script writes.
+
+Nothing from the reference is copied: this script imports its modules, feeds seeded inputs and
+stores inputs + outputs (data only).  Three absent third-party names are stubbed exactly as
+SURVEY.md §8(c)/F8 records (torchvision: imported-but-unused; timm DropPath/Mlp/to_2tuple:
+standard definitions; np.float alias removed in numpy>=1.24).
+"""
+import os
+import sys
+import types
+import random
+from functools import partial
+
+import numpy as np
+
+np.float = float  # models/pos_embed.py:52 uses the removed alias
+
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("SSL_AUDIO_REFERENCE", "/root/reference")
+
+
+def _install_stubs():
+    tv = types.ModuleType("torchvision")
+    tvd = types.ModuleType("torchvision.datasets")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.datasets, tv.transforms = tvd, tvt
+    sys.modules.update({"torchvision": tv, "torchvision.datasets": tvd, "torchvision.transforms": tvt})
+
+    class DropPath(nn.Module):  # rate is always 0 on this path -> identity
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    class Mlp(nn.Module):  # timm.models.vision_transformer.Mlp: fc1 -> act -> fc2
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.drop1 = nn.Dropout(drop)
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop2 = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+    names = ["timm", "timm.models", "timm.models.vision_transformer", "timm.models.layers",
+             "timm.models.layers.helpers"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["timm.models.vision_transformer"].DropPath = DropPath
+    mods["timm.models.vision_transformer"].Mlp = Mlp
+    mods["timm.models.layers.helpers"].to_2tuple = lambda x: tuple(x) if isinstance(x, (list, tuple)) else (x, x)
+    sys.modules.update(mods)
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+
+import augmentations as ref_aug  # noqa: E402
+import model as ref_model  # noqa: E402
+from utils import loss as ref_loss, utils as ref_utils, transforms as ref_transforms  # noqa: E402
+from utils import hyperparameters as ref_hp  # noqa: E402
+from models import mae as ref_mae, pos_embed as ref_pos  # noqa: E402
+
+
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def t2n(t):
+    return t.detach().cpu().clone().numpy()  # clone: later in-place updates must not alias a saved vector
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def cfg_ns(**kw):
+    a = ref_hp.get_std_parameters().parse_args([])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+# ----------------------------------------------------------------------------- BT loss
+def gen_bt_loss():
+    out = {}
+    for tag, B, D, hsic in [("anchor", 64, 256, False), ("hsic", 64, 256, True), ("cfg1", 32, 256, False),
+                            ("ragged", 7, 24, False)]:
+        torch.manual_seed(0)
+        z1 = torch.randn(B, D)
+        z2 = z1 + 0.1 * torch.randn(B, D)
+        z1.requires_grad_(True)
+        z2.requires_grad_(True)
+        cfg = cfg_ns(projector_out_dim=D, alpha=1.0, lmbda=0.005, HSIC=hsic)
+        crit = ref_loss.BarlowTwinsLoss(cfg, ncrops=2)
+        l = crit.forward_loss(z1, z2)
+        l.backward()
+        out.update({f"{tag}_z1": t2n(z1), f"{tag}_z2": t2n(z2), f"{tag}_loss": t2n(l),
+                    f"{tag}_dz1": t2n(z1.grad), f"{tag}_dz2": t2n(z2.grad),
+                    f"{tag}_running_mean": t2n(crit.bn.running_mean), f"{tag}_running_var": t2n(crit.bn.running_var),
+                    f"{tag}_nbt": t2n(crit.bn.num_batches_tracked), f"{tag}_hsic": np.array(int(hsic))})
+    # BarlowTwinsLoss.forward crop bookkeeping: (g=1, L=0), (g=1, L=1), (g=2, L=0)
+    for tag, g, L in [("g1L0", 1, 0), ("g1L1", 1, 1), ("g2L0", 2, 0)]:
+        torch.manual_seed(3)
+        B, D = 16, 32
+        ncrops = L + 2
+        n_student = ncrops - (2 - g)
+        student = torch.randn(n_student * B, D, requires_grad=True)
+        teacher = torch.randn(g * B, D, requires_grad=True)
+        cfg = cfg_ns(projector_out_dim=D, alpha=1.0, lmbda=0.005, HSIC=False)
+        crit = ref_loss.BarlowTwinsLoss(cfg, ncrops=ncrops)
+        l = crit(student, teacher, ngcrops_each=g)
+        l.backward()
+        out.update({f"fwd_{tag}_student": t2n(student), f"fwd_{tag}_teacher": t2n(teacher),
+                    f"fwd_{tag}_loss": t2n(l), f"fwd_{tag}_dstudent": t2n(student.grad),
+                    f"fwd_{tag}_dteacher": t2n(teacher.grad), f"fwd_{tag}_ncrops": np.array(ncrops),
+                    f"fwd_{tag}_g": np.array(g),
+                    f"fwd_{tag}_running_mean": t2n(crit.bn.running_mean),
+                    f"fwd_{tag}_running_var": t2n(crit.bn.running_var)})
+    x = torch.arange(25.0).reshape(5, 5)
+    out["offdiag_in"] = t2n(x)
+    out["offdiag_out"] = t2n(ref_utils.off_diagonal(x))
+    save("bt_loss", **out)
+
+
+# ----------------------------------------------------------------------------- augmentations
+class _Recorder:
+    """Wraps RandomResizeCrop.get_params to record the (i, j, h, w) actually drawn."""
+
+    def __init__(self):
+        self.params = []
+        self._orig = ref_aug.RandomResizeCrop.get_params
+
+    def __enter__(self):
+        orig = self._orig
+
+        def rec(*a, **k):
+            p = orig(*a, **k)
+            self.params.append([int(v) for v in p])
+            return p
+
+        ref_aug.RandomResizeCrop.get_params = staticmethod(rec)
+        return self
+
+    def __exit__(self, *a):
+        ref_aug.RandomResizeCrop.get_params = staticmethod(self._orig)
+
+
+def gen_augment():
+    out = {}
+    # log_mixup_exp
+    torch.manual_seed(1)
+    xa, xb = torch.randn(1, 64, 96) * 2 - 1, torch.randn(1, 64, 96) * 2 - 1
+    for k, alpha in enumerate([0.0, 0.13, 0.2, 1.0]):
+        out[f"lme_{k}_alpha"] = np.array(alpha)
+        out[f"lme_{k}_out"] = t2n(ref_aug.log_mixup_exp(xa, xb, alpha))
+    out["lme_xa"], out["lme_xb"] = t2n(xa), t2n(xb)
+
+    # RandomResizeCrop with recorded params: T=96 (default) and T=1001 (10 s), plus local-crop geometry
+    for tag, F_, T_, out_size, vcs, fs, ts, seed in [
+        ("t96", 64, 96, (64, 96), (1.0, 1.5), (0.6, 1.5), (0.6, 1.5), 123),
+        ("t96b", 64, 96, (64, 96), (1.0, 1.5), (0.6, 1.5), (0.6, 1.5), 7),
+        ("t1001", 64, 1001, (64, 1001), (1.0, 1.5), (0.6, 1.5), (0.6, 1.5), 11),
+        ("t1001b", 64, 1001, (64, 1001), (1.0, 1.5), (0.6, 1.5), (0.6, 1.5), 12),
+        ("local", 64, 96, (16, 16), (1.0, 1.0), (0.05, 0.6), (0.05, 0.6), 5),
+    ]:
+        seed_all(seed)
+        x = torch.randn(1, F_, T_)
+        rrc = ref_aug.RandomResizeCrop(out_size, virtual_crop_scale=vcs, freq_scale=fs, time_scale=ts)
+        with _Recorder() as r:
+            y = rrc(x)
+        out[f"rrc_{tag}_x"] = t2n(x)
+        out[f"rrc_{tag}_y"] = t2n(y)
+        out[f"rrc_{tag}_params"] = np.array(r.params[0])
+        out[f"rrc_{tag}_cfg"] = np.array([out_size[0], out_size[1], vcs[0], vcs[1], fs[0], fs[1], ts[0], ts[1], seed],
+                                         dtype=np.float64)
+
+    # RandomLinearFader
+    seed_all(9)
+    x = torch.randn(1, 64, 96)
+    st = np.random.get_state()
+    ht = 1.0 * ((2.0 * np.random.rand(2)) - 1.0)
+    np.random.set_state(st)
+    y = ref_aug.RandomLinearFader()(x)
+    out["rlf_x"], out["rlf_y"], out["rlf_head_tail"] = t2n(x), t2n(y), ht
+
+    # NormalizeBatch
+    torch.manual_seed(2)
+    X = torch.randn(5, 1, 64, 96) * 3 + 1
+    out["nb_x"], out["nb_y"] = t2n(X), t2n(ref_aug.NormalizeBatch()(X))
+
+    # Whole AudioPairTransform sequence: 5 consecutive clips (bank evolution, RNG call order)
+    for tag, T_, L in [("seq96", 96, 0), ("seq208", 208, 0), ("seq96_local", 96, 2)]:
+        seed_all(42)
+        args = cfg_ns(crop_frames=T_, local_crops_number=L)
+        tfm = ref_transforms.AudioPairTransform(args)
+        clips = torch.randn(5, 1, 64, T_) * 1.3 - 0.2
+        views, locals_ = [], []
+        with _Recorder() as r:
+            for c in clips:
+                crops = tfm(c)
+                views.append(torch.stack(crops[:2]))
+                if L:
+                    locals_.append(torch.stack(crops[2:]))
+        out[f"apt_{tag}_clips"] = t2n(clips)
+        out[f"apt_{tag}_views"] = t2n(torch.stack(views))          # [5, 2, 1, 64, T]
+        if L:
+            out[f"apt_{tag}_locals"] = t2n(torch.stack(locals_))   # [5, L, 1, 16, 16]
+        out[f"apt_{tag}_rrc_params"] = np.array(r.params)          # draws in call order
+        out[f"apt_{tag}_seed"] = np.array(42)
+        out[f"apt_{tag}_L"] = np.array(L)
+    save("augment", **out)
+
+
+# ----------------------------------------------------------------------------- ViT (micro) + pos-embed
+def micro_vit(use_decoder=False, img_size=(64, 96), embed_dim=64, depth=2, heads=2):
+    return ref_mae.MaskedAutoencoderViT(
+        img_size=img_size, patch_size=[16, 16], in_chans=1, embed_dim=embed_dim, depth=depth, num_heads=heads,
+        mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_decoder=use_decoder,
+        decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=2)
+
+
+def perturb_(m, seed):
+    """Make every parameter (biases, LN affine, k-less qkv bias) non-trivial so parity tests see them."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "pos_embed" in n:
+                continue
+            if p.dim() == 1 or n.endswith("cls_token") or n.endswith("mask_token"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def gen_vit():
+    out = {}
+    torch.manual_seed(0)
+    m = micro_vit()
+    perturb_(m, 1)
+    m.eval()
+    for k, v in m.state_dict().items():
+        out["sd." + k] = t2n(v)
+    for tag, T_ in [("t96", 96), ("t208", 208), ("t1001", 1001)]:
+        torch.manual_seed(10)
+        x = torch.randn(2, 1, 64, T_)
+        x.requires_grad_(True)
+        lat = m(x)
+        out[f"{tag}_x"], out[f"{tag}_latent"] = t2n(x), t2n(lat)
+        tok, _, _ = m.prepare_tokens(x, 0)
+        out[f"{tag}_tokens"] = t2n(tok)
+        out[f"{tag}_pos"] = t2n(m.interpolate_pos_encoding(m.patch_embed(x), 64, T_))
+        out[f"{tag}_latent_meanpool"] = t2n(m(x, mean_pool=True))
+        full, _, _ = m.forward_encoder(x, 0)
+        out[f"{tag}_encoded"] = t2n(full)
+        # backward through the encoder: grads of a few named params for sum(latent * w)
+        m.zero_grad()
+        w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+        (lat * w).sum().backward()
+        for pn in ["cls_token", "blocks.0.attn.qkv.weight", "blocks.0.attn.q_bias", "blocks.0.attn.v_bias",
+                   "blocks.1.mlp.fc1.weight", "blocks.1.mlp.fc2.bias", "blocks.0.norm1.weight", "norm.bias",
+                   "blocks.1.attn.proj.weight"]:
+            out[f"{tag}_grad.{pn}"] = t2n(dict(m.named_parameters())[pn].grad)
+    # masked forward with a prefixed mask (models/mae.py:317-323) -> deterministic
+    torch.manual_seed(11)
+    x = torch.randn(3, 1, 64, 96)
+    mask = torch.zeros(3, 24)
+    for b in range(3):
+        mask[b, torch.randperm(24)[:18]] = 1  # 75 % masked, 6 kept
+    lat = m(x, mask_ratio=mask)
+    out["mask_x"], out["mask_mask"], out["mask_latent"] = t2n(x), t2n(mask), t2n(lat)
+    xm, mk, ids = m.random_masking(m.patch_embed(x), mask)
+    out["mask_ids_restore"] = t2n(ids)
+    out["mask_out_mask"] = t2n(mk)
+    # masked forward with the internal torch.rand noise: capture by seeding
+    torch.manual_seed(77)
+    noise = torch.rand(3, 24)
+    torch.manual_seed(77)
+    lat2 = m(x, mask_ratio=0.75)
+    out["rand_noise"], out["rand_latent"] = t2n(noise), t2n(lat2)
+    # positional tables at real sizes (init-time constants)
+    out["sincos_192_4x6"] = ref_pos.get_2d_sincos_pos_embed(192, (4, 6)).astype(np.float32)
+    out["sincos_768_4x6"] = ref_pos.get_2d_sincos_pos_embed(768, (4, 6)).astype(np.float32)
+    out["sinusoid_24_384"] = ref_pos.get_sinusoid_encoding_table(24, 384).astype(np.float32)
+    save("vit_micro", **out)
+
+    # MAE decoder + recon loss (reference path T=96, and cfg-5 style img_size=(64, 992) scaled down to (64,208))
+    out = {}
+    for tag, img in [("t96", (64, 96)), ("t208", (64, 208))]:
+        torch.manual_seed(5)
+        md = micro_vit(use_decoder=True, img_size=img)
+        perturb_(md, 2)
+        for k, v in md.state_dict().items():
+            out[f"{tag}_sd." + k] = t2n(v)
+        L = (img[0] // 16) * (img[1] // 16)
+        torch.manual_seed(6)
+        x = torch.randn(2, 1, img[0], img[1])
+        mask = torch.zeros(2, L)
+        keep = int(L * 0.25)
+        for b in range(2):
+            mask[b, torch.randperm(L)[:L - keep]] = 1
+        lat, rl = md(x, mask_ratio=mask, masked_recon=True)
+        md.zero_grad()
+        (rl + lat.sum() * 0.01).backward()
+        out[f"{tag}_x"], out[f"{tag}_mask"] = t2n(x), t2n(mask)
+        out[f"{tag}_latent"], out[f"{tag}_recon_loss"] = t2n(lat), t2n(rl)
+        out[f"{tag}_patchify"] = t2n(md.patchify(x))
+        for pn in ["mask_token", "decoder_embed.weight", "decoder_pred.bias", "decoder_blocks.0.attn.qkv.weight",
+                   "blocks.0.mlp.fc1.weight"]:
+            out[f"{tag}_grad.{pn}"] = t2n(dict(md.named_parameters())[pn].grad)
+    save("mae_micro", **out)
+
+
+# ----------------------------------------------------------------------------- head / predictor
+def gen_head():
+    out = {}
+    cfg = cfg_ns(projector_hidden_dim=96, projector_out_dim=32, projector_n_hidden_layers=1)
+    torch.manual_seed(0)
+    head = ref_model.BarlowTwinsHead(cfg, in_dim=48)
+    with torch.no_grad():
+        head.projector[1].weight.add_(0.2 * torch.randn(96))
+        head.projector[1].bias.add_(0.2 * torch.randn(96))
+    for k, v in head.state_dict().items():
+        out["head_sd." + k] = t2n(v)
+    x = torch.randn(2 * 12, 48, requires_grad=True)
+    z = head(x, ncrops=2)
+    w = torch.randn_like(z)
+    (z * w).sum().backward()
+    out.update(head_x=t2n(x), head_z=t2n(z), head_w=t2n(w), head_dx=t2n(x.grad))
+    for n, p in head.named_parameters():
+        out["head_grad." + n] = t2n(p.grad)
+    for k, v in head.state_dict().items():
+        out["head_sd_after." + k] = t2n(v)
+    torch.manual_seed(1)
+    pred = ref_model.BarlowTwinsPredictor(32, use=True)
+    for k, v in pred.state_dict().items():
+        out["pred_sd." + k] = t2n(v)
+    x = torch.randn(2 * 12, 32, requires_grad=True)
+    z = pred(x, ncrops=1)
+    w = torch.randn_like(z)
+    (z * w).sum().backward()
+    out.update(pred_x=t2n(x), pred_z=t2n(z), pred_w=t2n(w), pred_dx=t2n(x.grad))
+    for n, p in pred.named_parameters():
+        out["pred_grad." + n] = t2n(p.grad)
+    save("head", **out)
+
+
+# ----------------------------------------------------------------------------- one full training step
+class _MicroBackbone(nn.Module):
+    """ModelWrapper-shaped backbone around the micro ViT (ModelWrapper itself hard-codes tiny/small/base)."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = micro_vit()
+        self.feature_dim = self.encoder.embed_dim
+
+    def forward(self, x, mask_ratio=0, masked_recon=False):
+        return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon)
+
+
+def gen_step():
+    """main_bt_byol.py:79-135 with --stop_gradient --predictor, and the plain two-net variant, B=8, T=96."""
+    for tag, stop_grad, use_pred in [("byol", True, True), ("plain", False, False)]:
+        out = {}
+        cfg = cfg_ns(projector_hidden_dim=96, projector_out_dim=32, model_type="vit_tiny", batch_size=8)
+        ref_hp.setup_hyperparameters(cfg)
+        torch.manual_seed(0)
+        online = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 64))
+        perturb_(online, 3)
+        predictor = ref_model.BarlowTwinsPredictor(32, use=use_pred)
+        torch.manual_seed(1)
+        target = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 64))
+        target.load_state_dict(online.state_dict())
+        if stop_grad:
+            for p in target.parameters():
+                p.requires_grad = False
+        crit = ref_loss.BarlowTwinsLoss(cfg, ncrops=2)
+        groups = ref_utils.get_param_groups(online)
+        if use_pred:
+            groups += ref_utils.get_param_groups(predictor)
+        if not stop_grad:
+            groups += ref_utils.get_param_groups(target)
+        opt = torch.optim.AdamW(groups, lr=cfg.lr, weight_decay=cfg.wd)
+        for k, v in online.state_dict().items():
+            out["online_sd." + k] = t2n(v)
+        for k, v in predictor.state_dict().items():
+            out["pred_sd." + k] = t2n(v)
+        torch.manual_seed(4)
+        images = [torch.randn(8, 1, 64, 96), torch.randn(8, 1, 64, 96)]
+        out["view0"], out["view1"] = t2n(images[0]), t2n(images[1])
+        ema = ref_utils.EMA(0.99)
+        losses = []
+        for it in range(2):
+            o = online(images[:2], ncrops=2)
+            o = predictor(o, ncrops=1)
+            t = target(images, ncrops=2)
+            l = crit(o, t, ngcrops_each=2)
+            losses.append(float(l))
+            if stop_grad:
+                ref_utils.update_moving_average(ema, target, online)
+            opt.zero_grad()
+            l.backward()
+            if it == 0:
+                for pn in ["backbone.encoder.cls_token", "backbone.encoder.blocks.0.attn.qkv.weight",
+                           "backbone.encoder.blocks.1.mlp.fc2.weight", "head.projector.0.weight",
+                           "head.projector.1.weight", "head.projector.3.weight",
+                           "backbone.encoder.norm.weight"]:
+                    out["grad0." + pn] = t2n(dict(online.named_parameters())[pn].grad)
+            opt.step()
+        out["losses"] = np.array(losses)
+        out["lr"], out["wd"] = np.array(cfg.lr), np.array(cfg.wd)
+        for k, v in online.state_dict().items():
+            out["online_sd_after." + k] = t2n(v)
+        for k, v in target.state_dict().items():
+            out["target_sd_after." + k] = t2n(v)
+        for k, v in crit.state_dict().items():
+            out["crit_sd_after." + k] = t2n(v)
+        save(f"step_{tag}", **out)
+
+
+# ----------------------------------------------------------------------------- MultiCropWrapper grouping, EMA, param groups
+def gen_misc():
+    out = {}
+
+    class Bk(nn.Module):
+        def forward(self, x):
+            return x.mean(dim=(1, 2)).unsqueeze(1) * torch.ones(1, 3) + x.shape[-1]
+
+    class Hd(nn.Module):
+        def forward(self, x, ncrops):
+            return x * ncrops
+
+    mc = ref_utils.MultiCropWrapper(Bk(), Hd())
+    torch.manual_seed(0)
+    xs = [torch.randn(2, 4, 8), torch.randn(2, 4, 8), torch.randn(2, 4, 5), torch.randn(2, 4, 5), torch.randn(2, 4, 5)]
+    out["mc_out"] = t2n(mc(xs, ncrops=5))
+    for i, x in enumerate(xs):
+        out[f"mc_x{i}"] = t2n(x)
+    a, b = nn.Linear(4, 3), nn.Linear(4, 3)
+    out["ema_old_w"], out["ema_new_w"] = t2n(a.weight), t2n(b.weight)
+    ref_utils.update_moving_average(ref_utils.EMA(0.99), a, b)
+    out["ema_out_w"] = t2n(a.weight)
+    torch.manual_seed(0)
+    online = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(
+        cfg_ns(projector_hidden_dim=96, projector_out_dim=32), 64))
+    groups = ref_utils.get_param_groups(online)
+    names = {id(p): n for n, p in online.named_parameters()}
+    out["pg_regularized"] = np.array([names[id(p)] for p in groups[0]["params"]])
+    out["pg_not_regularized"] = np.array([names[id(p)] for p in groups[1]["params"]])
+    save("misc", **out)
+
+
+if __name__ == "__main__":
+    gen_bt_loss()
+    gen_augment()
+    gen_vit()
+    gen_head()
+    gen_step()
+    gen_misc()

@@ -1,0 +1,281 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as oaug
+from oracle import frontend as ofe
+from oracle import heads as oh
+from oracle import step as ostep
+from oracle import vit as ovit
+
+
+def T(a, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+# ----------------------------------------------------------------------------- BT loss
+@pytest.mark.parametrize("tag", ["anchor", "hsic", "cfg1", "ragged"])
+def test_bt_forward_loss(golden, tag):
+    g = golden("bt_loss")
+    z1, z2 = T(g[f"{tag}_z1"]).requires_grad_(True), T(g[f"{tag}_z2"]).requires_grad_(True)
+    hsic = bool(g[f"{tag}_hsic"])
+    loss, stats = oh.bt_forward_loss(z1, z2, 1.0, 0.005, hsic)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=2e-6)
+    np.testing.assert_allclose(z1.grad.numpy(), g[f"{tag}_dz1"], rtol=1e-4, atol=2e-8)
+    np.testing.assert_allclose(z2.grad.numpy(), g[f"{tag}_dz2"], rtol=1e-4, atol=2e-8)
+    # analytic backward agrees with the reference's autograd
+    l2, dz1, dz2 = oh.bt_forward_loss_backward(z1.detach().double(), z2.detach().double(), 1.0, 0.005, hsic)
+    np.testing.assert_allclose(l2.item(), g[f"{tag}_loss"], rtol=2e-6)
+    np.testing.assert_allclose(dz1.numpy(), g[f"{tag}_dz1"], rtol=2e-4, atol=5e-8)
+    np.testing.assert_allclose(dz2.numpy(), g[f"{tag}_dz2"], rtol=2e-4, atol=5e-8)
+    rm, rv, nbt = oh.bt_running_stats([(tuple(s.detach() for s in stats), z1.shape[0])], z1.shape[1])
+    np.testing.assert_allclose(rm.numpy(), g[f"{tag}_running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.numpy(), g[f"{tag}_running_var"], rtol=1e-5)
+    assert nbt == int(g[f"{tag}_nbt"])
+
+
+def test_bt_anchor_value(golden):
+    """Known-answer anchor recorded in SURVEY.md §8(c)."""
+    assert abs(float(golden("bt_loss")["anchor_loss"]) - 5.219377040863037) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["g1L0", "g1L1", "g2L0"])
+def test_bt_forward_crops(golden, tag):
+    g = golden("bt_loss")
+    st, te = T(g[f"fwd_{tag}_student"]).requires_grad_(True), T(g[f"fwd_{tag}_teacher"]).requires_grad_(True)
+    loss, stats = oh.bt_forward(st, te, int(g[f"fwd_{tag}_ncrops"]), int(g[f"fwd_{tag}_g"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"fwd_{tag}_loss"], rtol=3e-6)
+    np.testing.assert_allclose(st.grad.numpy(), g[f"fwd_{tag}_dstudent"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(te.grad.numpy(), g[f"fwd_{tag}_dteacher"], rtol=1e-4, atol=1e-7)
+    rm, rv, _ = oh.bt_running_stats([(tuple(s.detach() for s in s4), n) for s4, n in stats], st.shape[1])
+    np.testing.assert_allclose(rm.numpy(), g[f"fwd_{tag}_running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.numpy(), g[f"fwd_{tag}_running_var"], rtol=1e-5)
+
+
+def test_off_diagonal(golden):
+    g = golden("bt_loss")
+    np.testing.assert_array_equal(oh.off_diagonal(T(g["offdiag_in"])).numpy(), g["offdiag_out"])
+
+
+# ----------------------------------------------------------------------------- augmentations
+def test_log_mixup_exp(golden):
+    g = golden("augment")
+    for k in range(4):
+        y = oaug.log_mixup_exp(g["lme_xa"].astype(np.float64), g["lme_xb"].astype(np.float64), float(g[f"lme_{k}_alpha"]))
+        np.testing.assert_allclose(y, g[f"lme_{k}_out"], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["t96", "t96b", "t1001", "t1001b", "local"])
+def test_rrc(golden, tag):
+    g = golden("augment")
+    cfg = g[f"rrc_{tag}_cfg"]
+    out_size, vcs = (int(cfg[0]), int(cfg[1])), (cfg[2], cfg[3])
+    x = g[f"rrc_{tag}_x"]
+    # sampler: same seeds -> same (i, j, h, w)  (x itself consumed torch RNG only)
+    seed = int(cfg[8])
+    np_rng, py_rng = np.random.RandomState(seed), random.Random(seed)
+    canvas = oaug.canvas_size(x.shape[-2:], vcs)
+    p = oaug.draw_rrc_params(np_rng, py_rng, canvas, x.shape[-2:], (cfg[6], cfg[7]), (cfg[4], cfg[5]))
+    assert list(p) == list(g[f"rrc_{tag}_params"])
+    y = oaug.rrc_apply(x, p, out_size, vcs)
+    np.testing.assert_allclose(y, g[f"rrc_{tag}_y"], rtol=0, atol=3e-5)
+
+
+def test_rrc_anchor(golden):
+    """SURVEY.md §8(c) anchor: seeds 123, 64x96 in, canvas 64x144 -> (0, 3, 64, 82)."""
+    assert list(golden("augment")["rrc_t96_params"]) == [0, 3, 64, 82]
+
+
+def test_linear_fader(golden):
+    g = golden("augment")
+    y = oaug.linear_fader_apply(g["rlf_x"].astype(np.float64), *g["rlf_head_tail"])
+    np.testing.assert_allclose(y, g["rlf_y"], atol=1e-6)
+
+
+def test_normalize_batch(golden):
+    g = golden("augment")
+    np.testing.assert_allclose(oaug.normalize_batch(g["nb_x"]), g["nb_y"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["seq96", "seq208", "seq96_local"])
+def test_audio_pair_transform_sequence(golden, tag):
+    """Bank evolution + RNG call order over 5 consecutive clips."""
+    g = golden("augment")
+    clips = g[f"apt_{tag}_clips"]
+    L = int(g[f"apt_{tag}_L"])
+    tfm = oaug.PairTransformOracle(crop_frames=clips.shape[-1], local_crops_number=L, seed=int(g[f"apt_{tag}_seed"]))
+    rrc_seen = []
+    for k, c in enumerate(clips):
+        crops = tfm(c)
+        for v in range(2):
+            np.testing.assert_allclose(crops[v], g[f"apt_{tag}_views"][k, v], atol=5e-5)
+        for l in range(L):
+            np.testing.assert_allclose(crops[2 + l], g[f"apt_{tag}_locals"][k, l], atol=5e-5)
+    rrc_seen = [list(r["rrc"]) for r in tfm.records]
+    assert rrc_seen == g[f"apt_{tag}_rrc_params"].tolist()
+    assert tfm.records[0]["bank_index"] == -1 and tfm.records[1]["bank_index"] == 0
+    assert len(tfm.bank) == 10
+
+
+# ----------------------------------------------------------------------------- frontend (parity unpinned: self-consistency only)
+def test_frontend_matches_torch_stft():
+    rng = np.random.RandomState(0)
+    wave = (0.1 * rng.randn(2, 16000)).astype(np.float32)
+    p = ofe.power_spectrogram(wave)
+    st = torch.stft(torch.from_numpy(wave).double(), 1024, 160, 1024, torch.hann_window(1024, periodic=True, dtype=torch.float64),
+                    center=True, pad_mode="reflect", return_complex=True)
+    np.testing.assert_allclose(p, (st.abs() ** 2).numpy(), rtol=1e-9, atol=1e-12)
+    assert ofe.logmel(wave).shape == (2, 64, 101)
+    assert ofe.n_frames(160000) == 1001 and ofe.n_frames(15200) == 96
+
+
+def test_mel_filterbank_shape_and_partition():
+    fb = ofe.mel_filterbank()
+    assert fb.shape == (513, 64) and fb.min() >= 0
+    assert (fb > 0).sum(1).max() <= 2          # each bin feeds at most two triangles
+    np.testing.assert_allclose(fb[40:480].sum(1), 1.0, atol=1e-9)  # interior bins: the two slopes sum to 1
+
+
+def test_crop_pad_normalize():
+    x = np.arange(2 * 5, dtype=np.float64).reshape(1, 2, 5)
+    np.testing.assert_allclose(ofe.crop_pad_normalize(x, 3, 1, 1.0, 2.0), (x[..., 1:4] - 1) / 2)
+    y = ofe.crop_pad_normalize(x, 7, 0, 1.0, 2.0)
+    assert y.shape[-1] == 7 and np.allclose(y[..., 5:], -0.5)
+
+
+# ----------------------------------------------------------------------------- ViT micro
+def _vit_params(g, prefix="sd."):
+    return {k[len(prefix):]: T(v) for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_pos_tables(golden):
+    g = golden("vit_micro")
+    np.testing.assert_allclose(ovit.sincos_2d(192, (4, 6)), g["sincos_192_4x6"], atol=1e-6)
+    np.testing.assert_allclose(ovit.sincos_2d(768, (4, 6)), g["sincos_768_4x6"], atol=1e-6)
+    np.testing.assert_allclose(ovit.sinusoid_table(24, 384), g["sinusoid_24_384"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,T_", [("t96", 96), ("t208", 208), ("t1001", 1001)])
+def test_vit_forward_backward(golden, tag, T_):
+    g = golden("vit_micro")
+    p = _vit_params(g)
+    names = [k[len(f"{tag}_grad."):] for k in g if k.startswith(f"{tag}_grad.")]
+    for n in names:
+        p[n].requires_grad_(True)
+    x = T(g[f"{tag}_x"])
+    pos = ovit.interpolate_pos_embed(p["pos_embed"].numpy(), (4, 6), 64, T_)
+    np.testing.assert_allclose(pos, g[f"{tag}_pos"], atol=2e-6)
+    tok, _, _ = ovit.prepare_tokens(x, p, (4, 6))
+    np.testing.assert_allclose(tok.detach().numpy(), g[f"{tag}_tokens"], atol=1e-5)
+    enc, _, _ = ovit.forward_encoder(x, p, 2, (4, 6))
+    np.testing.assert_allclose(enc.detach().numpy(), g[f"{tag}_encoded"], atol=5e-5)
+    lat = ovit.forward(x, p, 2, (4, 6))
+    np.testing.assert_allclose(lat.detach().numpy(), g[f"{tag}_latent"], atol=5e-5)
+    np.testing.assert_allclose(ovit.forward(x, p, 2, (4, 6), mean_pool=True).detach().numpy(), g[f"{tag}_latent_meanpool"], atol=5e-5)
+    w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+    (lat * w).sum().backward()
+    for n in names:
+        np.testing.assert_allclose(p[n].grad.numpy(), g[f"{tag}_grad.{n}"], rtol=2e-3, atol=2e-5, err_msg=n)
+
+
+def test_vit_masking(golden):
+    g = golden("vit_micro")
+    p = _vit_params(g)
+    x = T(g["mask_x"])
+    lat = ovit.forward(x, p, 2, (4, 6), mask=T(g["mask_mask"]))
+    np.testing.assert_allclose(lat.numpy(), g["mask_latent"], atol=5e-5)
+    _, m, ids = ovit.masking_from_noise(ovit.patch_embed(x, p), mask=T(g["mask_mask"]))
+    np.testing.assert_array_equal(ids.numpy(), g["mask_ids_restore"])
+    np.testing.assert_array_equal(m.numpy(), g["mask_out_mask"])
+    lat2 = ovit.forward(x, p, 2, (4, 6), noise=T(g["rand_noise"]), mask_ratio=0.75)
+    np.testing.assert_allclose(lat2.numpy(), g["rand_latent"], atol=5e-5)
+
+
+@pytest.mark.parametrize("tag,grid", [("t96", (4, 6)), ("t208", (4, 13))])
+def test_mae_decoder(golden, tag, grid):
+    g = golden("mae_micro")
+    p = _vit_params(g, f"{tag}_sd.")
+    names = [k[len(f"{tag}_grad."):] for k in g if k.startswith(f"{tag}_grad.")]
+    for n in names:
+        p[n].requires_grad_(True)
+    x = T(g[f"{tag}_x"])
+    np.testing.assert_array_equal(ovit.patchify(x, grid).numpy(), g[f"{tag}_patchify"])
+    lat, rl = ovit.forward(x, p, 2, grid, mask=T(g[f"{tag}_mask"]), masked_recon=True, dec_heads=2)
+    np.testing.assert_allclose(lat.detach().numpy(), g[f"{tag}_latent"], atol=5e-5)
+    np.testing.assert_allclose(rl.item(), g[f"{tag}_recon_loss"], rtol=1e-5)
+    (rl + lat.sum() * 0.01).backward()
+    for n in names:
+        np.testing.assert_allclose(p[n].grad.numpy(), g[f"{tag}_grad.{n}"], rtol=2e-3, atol=2e-6, err_msg=n)
+
+
+# ----------------------------------------------------------------------------- head / predictor
+def test_head_and_predictor(golden):
+    g = golden("head")
+    for pre, fwd, nc in [("head", oh.head_forward, 2), ("pred", oh.predictor_forward, 1)]:
+        sd = {k[len(pre + "_sd."):]: T(v) for k, v in g.items() if k.startswith(pre + "_sd.")}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+        x = T(g[pre + "_x"]).requires_grad_(True)
+        z, stats = fwd(x, sd, ncrops=nc)
+        np.testing.assert_allclose(z.detach().numpy(), g[pre + "_z"], atol=2e-5)
+        (z * T(g[pre + "_w"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), g[pre + "_dx"], rtol=1e-3, atol=2e-6)
+        for k, v in leaves.items():
+            np.testing.assert_allclose(v.grad.numpy(), g[f"{pre}_grad.{k}"], rtol=2e-3, atol=5e-6, err_msg=k)
+    # running stats after two chunk calls
+    sd = {k[len("head_sd."):]: T(v) for k, v in g.items() if k.startswith("head_sd.")}
+    x = T(g["head_x"])
+    _, stats = oh.head_forward(x, sd, ncrops=2)
+    st = {"projector.1.running_mean": sd["projector.1.running_mean"].clone(), "projector.1.running_var": sd["projector.1.running_var"].clone(),
+          "projector.1.num_batches_tracked": sd["projector.1.num_batches_tracked"].clone()}
+    ostep.apply_bn_buffers(st, "projector.1.", stats)
+    np.testing.assert_allclose(st["projector.1.running_mean"].numpy(), g["head_sd_after.projector.1.running_mean"], atol=1e-6)
+    np.testing.assert_allclose(st["projector.1.running_var"].numpy(), g["head_sd_after.projector.1.running_var"], rtol=1e-5)
+    assert int(st["projector.1.num_batches_tracked"]) == int(g["head_sd_after.projector.1.num_batches_tracked"])
+
+
+# ----------------------------------------------------------------------------- full step
+@pytest.mark.parametrize("tag,stop_grad,use_pred", [("byol", True, True), ("plain", False, False)])
+def test_full_step(golden, tag, stop_grad, use_pred):
+    g = golden(f"step_{tag}")
+
+    def load(prefix):
+        out = {}
+        for k, v in g.items():
+            if k.startswith(prefix):
+                t = torch.from_numpy(np.asarray(v))
+                out[k[len(prefix):]] = t.clone()
+        return out
+
+    online, pred = load("online_sd."), load("pred_sd.")
+    target = {k: v.clone() for k, v in online.items()}
+    views = [T(g["view0"]), T(g["view1"])]
+    opt = ostep.AdamW(float(g["lr"]), float(g["wd"]))
+    losses = []
+    for it in range(2):
+        l, grads = ostep.bt_byol_step(online, target, pred, views, 2, (4, 6), opt, stop_grad, use_pred)
+        losses.append(l)
+        if it == 0:
+            for k in [k for k in g if k.startswith("grad0.")]:
+                np.testing.assert_allclose(grads[k[len("grad0."):]].numpy(), g[k], rtol=5e-3, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4)
+    for k, v in g.items():
+        if k.startswith("online_sd_after."):
+            np.testing.assert_allclose(online[k[len("online_sd_after."):]].numpy(), v, rtol=1e-3, atol=2e-5, err_msg=k)
+        if k.startswith("target_sd_after."):
+            np.testing.assert_allclose(target[k[len("target_sd_after."):]].numpy(), v, rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_misc(golden):
+    g = golden("misc")
+    assert ostep.multicrop_groups([8, 8, 5, 5, 5]) == [(0, 2), (2, 5)]
+    np.testing.assert_allclose(0.99 * g["ema_old_w"] + 0.01 * g["ema_new_w"], g["ema_out_w"], atol=1e-7)
+    reg, noreg = ostep.split_param_groups(
+        [(str(n), (torch.zeros(2, 2) if str(n) in set(g["pg_regularized"].tolist()) else torch.zeros(2)).requires_grad_(True))
+         for n in list(g["pg_regularized"]) + list(g["pg_not_regularized"])])
+    assert reg == g["pg_regularized"].tolist() and noreg == g["pg_not_regularized"].tolist()
