@@ -1,0 +1,156 @@
+/* ssl_audio_hip.h -- C ABI of libssl_audio_hip.so (gfx950 / MI355X only).
+ *
+ * The drop-in boundary of the Audio Barlow Twins pre-training hot path.  The reference
+ * (jonahanton/SSL_audio) has no FFI: its boundary is the Python import surface consumed by
+ * main_bt_byol.py:20-25.  Every entry point below therefore cites the reference
+ * *op site* it replaces (file:line of the PyTorch call that does the work there).  The Python host side
+ * in ssl_audio_amd/ mirrors the reference's classes and calls these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is enqueued, never synchronised;
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS;
+ *   - bf16 tensors are raw 16-bit storage (`void*`), fp32 tensors are `float*`;
+ *   - return 0 on success; non-zero on failure with a message in sa_last_error().
+ *   - no entry point allocates, frees or synchronises (safe to capture into a hipGraph).
+ */
+#ifndef SSL_AUDIO_HIP_H
+#define SSL_AUDIO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sa_last_error(void);
+int sa_abi_version(void);
+/* fills name (e.g. "gfx950:sramecc+:xnack-") and CU count of the current device; host call */
+int sa_device_info(char* name_host, int name_len, int* cu_count_host);
+
+/* ------------------------------------------------------------------ GEMM (bf16 MFMA, fp32 accumulate)
+ * D[M,N] = epilogue( alpha * A . B ),  A: M x K, B: K x N in the maths; storage selected per operand:
+ *   a_kmajor=1: A stored [M][K] (k contiguous)       a_kmajor=0: A stored [K][M]
+ *   b_kmajor=1: B stored [N][K] (nn.Linear weight)   b_kmajor=0: B stored [K][N]
+ * Replaces F.linear / nn.Linear fwd+bwd at models/mae.py:128,138 (qkv, proj), timm Mlp fc1/fc2
+ * (models/mae.py:155,162), PatchEmbed conv-as-GEMM (models/mae.py:42), projector/predictor Linear
+ * (model.py:19,23,41,44), MAE decoder_embed / decoder_pred (models/mae.py:413,430).
+ * Epilogue order: v = alpha*acc; v += bias[n]; act; v += residual[row_r][n]; store.
+ */
+typedef struct SaGemmArgs {
+  const void* A; int64_t lda; int32_t a_kmajor;
+  const void* B; int64_t ldb; int32_t b_kmajor;
+  int32_t M, N, K;
+  float alpha;
+  const float* bias;            /* [N] fp32 or NULL */
+  int32_t act;                  /* 0 none | 1 GELU(erf); pre-activation copied to aux_out if non-NULL
+                                   | 2 multiply by GELU'(aux_in[m][n]) (backward through fc1's activation) */
+  const void* aux_in;           /* bf16 [M][ldaux] */
+  void* aux_out;                /* bf16 [M][ldaux] */
+  int64_t ldaux;
+  const float* residual;        /* fp32 or NULL; row = res_mod > 0 ? m % res_mod : m */
+  int64_t ldr; int32_t res_mod;
+  float* out_f32; int64_t ldo_f32;   /* either or both outputs may be given */
+  void* out_bf16; int64_t ldo_bf16;
+  int32_t row_group;            /* > 0: output row = m + m / row_group + 1 (patch tokens skip each clip's CLS row) */
+  int32_t split_k;              /* >= 1.  > 1: K is split over workgroups and partial tiles are atomically
+                                   ADDED into out_f32 (caller zeroes / owns accumulation); only alpha is applied */
+  int32_t accumulate;           /* split_k == 1 only: out_f32 += v instead of = v */
+} SaGemmArgs;
+int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
+
+/* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
+int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients); accumulate != 0 adds */
+int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
+
+
+/* ------------------------------------------------------------------ LayerNorm (fp32 stream -> bf16/fp32)
+ * Replaces nn.LayerNorm(eps=1e-6) at models/mae.py:149,153,208,227 (fwd + bwd).  One wave per row, D <= 2048.
+ * bwd: dx = dres + LN'(dy); dgamma/dbeta are ATOMICALLY ADDED into (caller zeroes or accumulates). */
+int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                     int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, float eps, void* stream);
+int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                     const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
+                     int64_t lddx, float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------ fused attention (head_dim 64, N <= 256)
+ * Replaces models/mae.py:130-138 (reshape/permute, q k^T * scale, softmax, attn v, transpose/reshape).
+ * qkv: bf16 [rows][ld], per row [q(C) | k(C) | v(C)], C = H*64, rows = sequences * N.  out: bf16 [rows][ldo].
+ * lse: fp32 [sequences*H][N] log-sum-exp of the scaled scores (saved for backward; may be NULL in fwd).
+ * bwd writes dqkv in the same packed layout as qkv (every element of the [rows][3C] block is written). */
+int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, void* out,
+                     int64_t ldo, float* lse, void* stream);
+int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, const void* out,
+                     const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d pieces (train mode, fp32)
+ * Replaces nn.BatchNorm1d at model.py:20,42 (projector / predictor, affine + ReLU) and utils/loss.py:13,17
+ * (loss, affine=False).  Split into statistics -> [host-side cross-rank combine] -> apply so one code path
+ * serves 1 GPU and the global-batch-exact data-parallel mode.
+ *   colstats : mean[c], m2[c] = sum_b (x - mean)^2 over the LOCAL rows
+ *   apply    : y = (x - mean) * rstd [* gamma + beta] [ReLU] -> fp32 and/or bf16
+ *   bwd_stats: s1[c] = sum_b g, s2[c] = sum_b g*xhat, g = dy * [ReLU mask]  (dbeta = s1, dgamma = s2)
+ *   bwd_apply: dx = gamma * rstd * (g - s1*inv_n - xhat * s2*inv_n), s1/s2 summed over ranks, inv_n = 1/global rows */
+int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, float* mean, float* m2, void* stream);
+int sa_bn_apply(const float* x, int64_t ld, int32_t B, int32_t C, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, int32_t relu, float* y_f32, void* y_bf16, int64_t ldy, void* stream);
+int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
+                    const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, float* s1,
+                    float* s2, void* stream);
+int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
+                    const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* s1,
+                    const float* s2, float inv_n, float* dx_f32, void* dx_bf16, int64_t lddx, void* stream);
+
+/* ------------------------------------------------------------------ Barlow Twins loss pieces (fp32, exact-fp32 MFMA)
+ * Replaces utils/loss.py:15-30.  sa_matmul_f32: C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
+ * (c = z1n^T z2n / B, dz1n = z2n G^T / B, dz2n = z1n G / B).  sa_bt_loss_grad: loss (1 float, overwritten) and
+ * G = dL/dc from the (already all-reduced) cross-correlation matrix c [D][D]; G may be NULL. */
+int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
+                  int32_t M, int32_t N, int32_t K, float alpha, void* stream);
+int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream);
+
+/* ------------------------------------------------------------------ optimiser / EMA on flat fp32 buffers
+ * AdamW: torch.optim.AdamW semantics (main_bt_byol.py:312-313); p_bf16 (optional) receives the bf16 copy the
+ * next step's GEMMs read.  EMA: utils/utils.py:317-331 (target = beta*target + (1-beta)*online). */
+int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream);
+int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream);
+
+/* ------------------------------------------------------------------ log-mel frontend
+ * Replaces torchaudio MelSpectrogram + log at datasets.py:39-48,115 and crop/pad/normalise at datasets.py:342-354.
+ * wave [n_clips][wave_stride] fp32 -> out [n_clips][64][T_out] fp32 (clip stride out_stride).  Output frame t is
+ * source frame t + start; frames past the clip are the normalised zero pad.  Tables (host-built, uploaded once):
+ * window [1024]; twiddle [1024][2] = (cos, -sin)(2 pi k / 1024); mel_weights [maxlen][64]; mel_lo/mel_len [64]. */
+int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32_t n_samples, const float* window,
+                  const float* twiddle, const float* mel_weights, const int32_t* mel_lo, const int32_t* mel_len, float* out,
+                  int64_t out_stride, int32_t T_out, int32_t start, float mean, float stdv, int32_t hop, void* stream);
+
+/* ------------------------------------------------------------------ augmentation stack (one fused launch per batch of views)
+ * Replaces MixupBYOLA.forward / log_mixup_exp (augmentations.py:81-85,103-117), RandomResizeCrop.forward
+ * (augmentations.py:40-55) and RandomLinearFader.forward (augmentations.py:69-74) with explicit parameters.
+ * lms: base of the clip store (ring of normalised log-mels, clip k at lms + k*clip_stride, [F_in][T_in]);
+ * src_slot[v]: clip of view v; mix_slot[v]: bank clip to mix in, or -1 (NULL = no mixing);
+ * params [n_views][8] fp32 = (alpha, i, j, h, w, head, tail, 0); out [n_views][F_out][T_out].
+ * max_w_ratio >= max crop width / (T_out - 1) bounds the LDS source tile. */
+int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_slot, const int32_t* mix_slot, const float* params,
+                     float* out, int32_t n_views, int32_t F_in, int32_t T_in, int32_t canvas_h, int32_t canvas_w, int32_t F_out,
+                     int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream);
+/* NormalizeBatch (augmentations.py:229-232) over n contiguous floats; workspace2 = 2 doubles; shift ~ mean guess */
+int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream);
+/* [S][1][F][T] fp32 -> bf16 patch rows [S*(F/ph)*(T/pw)][ph*pw] for the patch-embed GEMM (models/mae.py:42) */
+int sa_patchify_bf16(const float* img, void* out, int32_t S, int32_t F, int32_t T, int32_t ph, int32_t pw, void* stream);
+
+/* ------------------------------------------------------------------ token bookkeeping (fp32 residual stream [S][N][d])
+ * fill_cls: x[s][0][:] = cls + pos0 (models/mae.py:361-363); cls_grad: dcls += sum_s dx[s][0][:];
+ * gather_rows / scatter_add_rows: random-masking keep-gather and its adjoint, decoder un-shuffle
+ * (models/mae.py:335-337, 416-418); idx is [S][n_idx] int32, rows are offset by *_row0 inside each sequence. */
+int sa_fill_cls(float* x, int32_t S, int64_t seq_stride, int32_t d, const float* cls, const float* pos0, void* stream);
+int sa_cls_grad(const float* dx, int32_t S, int64_t seq_stride, int32_t d, float* dcls, void* stream);
+int sa_gather_rows(const float* src, int64_t src_seq_stride, int32_t src_row0, const int32_t* idx, int32_t n_idx, float* dst,
+                   int64_t dst_seq_stride, int32_t dst_row0, int32_t S, int32_t d, void* stream);
+int sa_scatter_add_rows(const float* src, int64_t src_seq_stride, int32_t src_row0, const int32_t* idx, int32_t n_idx, float* dst,
+                        int64_t dst_seq_stride, int32_t dst_row0, int32_t S, int32_t d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+// Fused multi-head self-attention forward / backward for the ViT encoder (head_dim 64, N <= 256 tokens).
+// Replaces models/mae.py:133-138: softmax(q k^T * hd^-0.5) v, reading q/k/v straight out of the packed
+// [rows, 3*C] qkv activation (no permute copies) and writing [rows, C] in the layout `proj` consumes.
+//
+// One workgroup (4 waves) per (sequence, head).  A 10 s clip is N = 249 tokens, so a whole head's K and V
+// (2 x 32 KiB bf16) sit in LDS and the softmax of a query row is exact (no online rescaling): each wave
+// takes 16-query tiles, keeps S^T = K Q^T for all keys in registers (query on the lane, keys in registers:
+// row max / sum are in-lane plus two cross-lane steps), and feeds P^T straight back as the MFMA operand of
+// O^T = V^T P^T (cdna_hip_programming.md §3 "accumulator tile as the next MFMA's operand").  V is consumed
+// through ds_read_b64_tr_b16, so no transposed copy exists anywhere.
+// Backward recomputes P from the saved log-sum-exp: pass A (wave owns query tiles) produces dQ, pass B
+// (wave owns key tiles) produces dK and dV, so no gradient is ever summed across waves or workgroups.
+#include "common.h"
+#include "../../include/ssl_audio_hip.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim
+constexpr int NMAX = 256;       // max tokens per sequence
+constexpr int IMG = NMAX * HD * 2;  // bytes of one [256][64] bf16 LDS image
+
+// ---- LDS image: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7)
+__device__ __forceinline__ int img_off(int row, int col) {  // col in elements, multiple of 4
+  return row * 128 + ((((col >> 3) ^ (row & 7))) << 4) + ((col >> 2) & 1) * 8;
+}
+
+// stage rows [0, nrows) of a strided global matrix (row stride ld elements, starting column col0) into an image
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* img, int ld, int col0, int nrows, int wave, int lane) {
+  const int ninstr = (nrows + 7) >> 3;
+  for (int q = wave; q < ninstr; q += 4) {
+    const int row = q * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const uint32_t voff = ((uint32_t)row * (uint32_t)ld + (uint32_t)(col0 + chunk * 8)) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(img + q * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// row read: lane gets M[row0 + (lane&15)][32*ks + 8*(lane>>4) .. +7]
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row0, int ks, int lane) {
+  const int r = row0 + (lane & 15);
+  const int kq = ks * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(img + r * 128 + ((kq ^ (r & 7)) << 4));
+}
+
+// transposing read: lane gets M[rows][col0 + (lane&15)] for rows {lo + 4g' .. } -- precisely:
+// element j < 4: row lo + 4*(lane>>4) + j ; element j >= 4: row hi + 4*(lane>>4) + (j - 4)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int lo, int hi, int col0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q = i >> 2, col = col0 + 4 * (i & 3);
+  const int r0 = lo + 4 * g + q, r1 = hi + 4 * g + q;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + img_off(r0, col)));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + img_off(r1, col)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  return r;
+}
+
+#define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
+
+// =====================================================================================================
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+                                                          float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kimg = smem;
+  char* Vimg = smem + IMG;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t row_base = (int64_t)s * N;
+  const bf16_t* base = qkv + row_base * ld;
+  const uint32_t bytes = (uint32_t)(((total_rows - row_base - 1) * ld + 3 * C) * 2);
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
+
+  const int nkt = (N + 15) >> 4;           // 16-key tiles
+  const int nks = (N + 31) >> 5;           // 32-key steps for P.V
+  stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane);
+  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g = lane >> 4, c = lane & 15;
+  for (int qt = wave; qt < nkt; qt += 4) {
+    // Q fragments for this lane's query (Y operand: k = d)
+    const int query = qt * 16 + c;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t voff = ((uint32_t)query * (uint32_t)ld + (uint32_t)(h * HD + 32 * ks + 8 * g)) * 2u;
+      auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+      qf[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
+    // S^T tiles: st[kt][r] = score(key = 16*kt + 4*g + r, query)
+    f32x4 st[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        st[kt] = MFMA16(row_frag(Kimg, kt * 16, 0, lane), qf[0], st[kt]);
+        st[kt] = MFMA16(row_frag(Kimg, kt * 16, 1, lane), qf[1], st[kt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float v = key < N ? st[kt][r] * scale : -INFINITY;
+          st[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
+          st[kt][r] = p;
+          sum += p;
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+    f32x4 ot[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      if (ps < nks) {
+        const bf16x8 pf = pack8(st[2 * ps], st[2 * ps + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = MFMA16(tr_frag(Vimg, 32 * ps, 32 * ps + 16, dt * 16, lane), pf, ot[dt]);
+      }
+    }
+    if (query < N) {
+      const float inv = 1.f / sum;
+      bf16_t* orow = out + (row_base + query) * ldo + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 o = {f2bf(ot[dt][0] * inv), f2bf(ot[dt][1] * inv), f2bf(ot[dt][2] * inv), f2bf(ot[dt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = o;
+      }
+      if (g == 0 && lse) lse[((int64_t)s * H + h) * N + query] = mx + __logf(sum);
+    }
+  }
+}
+
+// =====================================================================================================
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+                                                          float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, int ldo,
+                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qimg = smem;
+  char* Kimg = smem + IMG;
+  char* Vimg = smem + 2 * IMG;
+  char* Dimg = smem + 3 * IMG;                       // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
+  float* del_s = lse_s + NMAX;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t row_base = (int64_t)s * N;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + row_base * ld, (uint32_t)(((total_rows - row_base - 1) * ld + 3 * C) * 2));
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(dout + row_base * ldo, (uint32_t)(((total_rows - row_base - 1) * ldo + C) * 2));
+
+  const int nkt = (N + 15) >> 4;
+  const int nks = (N + 31) >> 5;
+  const int nrows = nks * 32;
+  stage_rows(rs, Qimg, ld, h * HD, nrows, wave, lane);
+  stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane);
+  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane);
+  stage_rows(rd, Dimg, ldo, h * HD, nrows, wave, lane);
+  // delta[q] = sum_d dO[q][d] * O[q][d]  (straight from global, one query row per thread), lse -> LDS
+  {
+    const int q = threadIdx.x;
+    float dl = 0.f, ls = 0.f;
+    if (q < N) {
+      const bf16x8* po = reinterpret_cast<const bf16x8*>(o + (row_base + q) * ldo + h * HD);
+      const bf16x8* pd = reinterpret_cast<const bf16x8*>(dout + (row_base + q) * ldo + h * HD);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 a = po[i], b = pd[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += bf2f(a[j]) * bf2f(b[j]);
+      }
+      ls = lse[((int64_t)s * H + h) * N + q];
+    }
+    del_s[q] = dl;
+    lse_s[q] = ls;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g = lane >> 4, c = lane & 15;
+
+  // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
+  for (int qt = wave; qt < nkt; qt += 4) {
+    const int query = qt * 16 + c;
+    const bf16x8 qf0 = row_frag(Qimg, qt * 16, 0, lane), qf1 = row_frag(Qimg, qt * 16, 1, lane);
+    const bf16x8 df0 = row_frag(Dimg, qt * 16, 0, lane), df1 = row_frag(Dimg, qt * 16, 1, lane);
+    const float lq = lse_s[query], dq_delta = del_s[query];
+    const bool qvalid = query < N;
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ps = 0; ps < nks; ++ps) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kt = 2 * ps + u;
+        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        sv = MFMA16(row_frag(Kimg, kt * 16, 0, lane), qf0, sv);
+        sv = MFMA16(row_frag(Kimg, kt * 16, 1, lane), qf1, sv);
+        dp = MFMA16(row_frag(Vimg, kt * 16, 0, lane), df0, dp);
+        dp = MFMA16(row_frag(Vimg, kt * 16, 1, lane), df1, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float p = (qvalid && key < N) ? __expf(sv[r] * scale - lq) : 0.f;
+          ds[u][r] = p * (dp[r] - dq_delta) * scale;
+        }
+      }
+      const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(tr_frag(Kimg, 32 * ps, 32 * ps + 16, dt * 16, lane), dsf, acc[dt]);
+    }
+    if (qvalid) {
+      bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v = {f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
+        *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int key = kt * 16 + c;
+    const bool kvalid = key < N;
+    const bf16x8 kf0 = row_frag(Kimg, kt * 16, 0, lane), kf1 = row_frag(Kimg, kt * 16, 1, lane);
+    const bf16x8 vf0 = row_frag(Vimg, kt * 16, 0, lane), vf1 = row_frag(Vimg, kt * 16, 1, lane);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qs = 0; qs < nks; ++qs) {
+      f32x4 pp[2], ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * qs + u;
+        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        sv = MFMA16(row_frag(Qimg, qt * 16, 0, lane), kf0, sv);   // D[query = 4g + r][key = c]
+        sv = MFMA16(row_frag(Qimg, qt * 16, 1, lane), kf1, sv);
+        dp = MFMA16(row_frag(Dimg, qt * 16, 0, lane), vf0, dp);
+        dp = MFMA16(row_frag(Dimg, qt * 16, 1, lane), vf1, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int query = qt * 16 + 4 * g + r;
+          const float p = (kvalid && query < N) ? __expf(sv[r] * scale - lse_s[query]) : 0.f;
+          pp[u][r] = p;
+          ds[u][r] = p * (dp[r] - del_s[query]) * scale;
+        }
+      }
+      const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = MFMA16(tr_frag(Dimg, 32 * qs, 32 * qs + 16, dt * 16, lane), pf, dv[dt]);    // dV^T[d][key]
+        dk[dt] = MFMA16(tr_frag(Qimg, 32 * qs, 32 * qs + 16, dt * 16, lane), dsf, dk[dt]);   // dK^T[d][key]
+      }
+    }
+    if (kvalid) {
+      bf16_t* krow = dqkv + (row_base + key) * ld + C + h * HD;
+      bf16_t* vrow = krow + C;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 a = {f2bf(dk[dt][0]), f2bf(dk[dt][1]), f2bf(dk[dt][2]), f2bf(dk[dt][3])};
+        bf16x4 b = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
+        *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
+        *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = b;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static int attn_check(const char* who, const void* qkv, int64_t rows, int64_t ld, int C, int H, int N) {
+  SA_CHECK_ARG(qkv && rows > 0, "%s: null/empty input", who);
+  SA_CHECK_ARG(H > 0 && C == H * HD, "%s: head_dim must be %d (C=%d, H=%d)", who, HD, C, H);
+  SA_CHECK_ARG(N > 0 && N <= NMAX, "%s: sequence length %d outside [1, %d]", who, N, NMAX);
+  SA_CHECK_ARG(rows % N == 0, "%s: rows=%lld not a multiple of N=%d", who, (long long)rows, N);
+  SA_CHECK_ARG(ld >= 3 * C && ld % 8 == 0 && ((uintptr_t)qkv & 15) == 0, "%s: qkv must have 16-byte aligned rows", who);
+  SA_CHECK_ARG((rows + NMAX) * ld * 2 < ((int64_t)1 << 32), "%s: qkv larger than the 4 GiB buffer-descriptor range", who);
+  return 0;
+}
+
+extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, void* out,
+                                int64_t ldo, float* lse, void* stream) {
+  if (attn_check("sa_attention_fwd", qkv, rows, ld, C, H, N)) return 1;
+  SA_CHECK_ARG(out && ldo >= C && ldo % 4 == 0, "sa_attention_fwd: bad output");
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+    configured = true;
+  }
+  const int S = (int)(rows / N);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(256), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
+                     (bf16_t*)out, (int)ldo, lse);
+  SA_LAUNCH_CHECK("sa_attention_fwd");
+  return 0;
+}
+
+extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, const void* out,
+                                const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream) {
+  if (attn_check("sa_attention_bwd", qkv, rows, ld, C, H, N)) return 1;
+  SA_CHECK_ARG(out && dout && lse && dqkv && ldo >= C && ldo % 8 == 0, "sa_attention_bwd: bad args");
+  SA_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)out & 15) == 0, "sa_attention_bwd: out/dout must be 16-byte aligned");
+  const int lds = 4 * IMG + 2 * NMAX * (int)sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    configured = true;
+  }
+  const int S = (int)(rows / N);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
+                     (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
+  SA_LAUNCH_CHECK("sa_attention_bwd");
+  return 0;
+}

@@ -1,0 +1,193 @@
+// Spectrogram augmentation stack on the GPU, one fused kernel per view:
+//   MixupBYOLA / log_mixup_exp (augmentations.py:81-85,103-117)
+//   -> RandomResizeCrop on a *virtual* zero canvas, bicubic align_corners=True (augmentations.py:40-55)
+//   -> RandomLinearFader (augmentations.py:69-74)
+// plus NormalizeBatch (augmentations.py:229-232) and the bf16 patch layout the patch-embed GEMM consumes.
+//
+// HBM-bound.  A workgroup owns an output slab [F_out x TT] of one view: it first materialises the source
+// columns that slab needs -- log-mixed once per source pixel, zero outside the pasted input -- as an LDS
+// tile (coalesced row reads of x and of the bank entry z), then every thread runs the 4x4 cubic taps out of
+// LDS and adds the fade slope.  The canvas is never built in memory.
+// Sampling is NOT done here: (alpha, bank slot, i, j, h, w, head, tail) arrive as explicit parameters so the
+// CPU oracle and this kernel consume identical draws.
+#include "common.h"
+#include "../../include/ssl_audio_hip.h"
+
+namespace {
+
+constexpr int LDS_W = 132;          // source columns per tile (incl. cubic halo)
+constexpr int LDS_H = 64;           // source rows per tile (crop height <= canvas height)
+constexpr float kEps32 = 1.1920929e-07f;
+constexpr float kA = -0.75f;        // PyTorch bicubic coefficient
+
+struct ViewParams {  // mirrored by ssl_audio_amd/augmentations.py (8 x float32 per view)
+  float alpha;       // mixup weight of the bank entry (0.2 * U[0,1)); ignored when mix_slot < 0
+  float i, j, h, w;  // crop rectangle on the virtual canvas (integers stored as float)
+  float head, tail;  // fader end points
+  float pad;
+};
+
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+  const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+  w[0] = ((kA * x0 - 5.f * kA) * x0 + 8.f * kA) * x0 - 4.f * kA;
+  w[1] = ((kA + 2.f) * t - (kA + 3.f)) * t * t + 1.f;
+  w[2] = ((kA + 2.f) * x2 - (kA + 3.f)) * x2 * x2 + 1.f;
+  w[3] = ((kA * x3 - 5.f * kA) * x3 + 8.f * kA) * x3 - 4.f * kA;
+}
+
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ lms, int64_t clip_stride, const int* __restrict__ src_slot,
+                                                      const int* __restrict__ mix_slot, const ViewParams* __restrict__ params,
+                                                      float* __restrict__ out, int F_in, int T_in, int canvas_h, int canvas_w, int F_out,
+                                                      int T_out, int TT, int do_fade) {
+  __shared__ float tile[LDS_H * LDS_W];
+  const int view = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int nt = min(TT, T_out - t0);
+  const ViewParams pr = params[view];
+  const int ci = (int)pr.i, cj = (int)pr.j, ch = (int)pr.h, cw = (int)pr.w;
+  const float* x = lms + (int64_t)src_slot[view] * clip_stride;
+  const int ms = mix_slot ? mix_slot[view] : -1;
+  const float* z = ms >= 0 ? lms + (int64_t)ms * clip_stride : nullptr;
+  const float wa = 1.f - pr.alpha, wb = pr.alpha;  // log_mixup_exp(x, z, 1 - alpha): weight of x is 1 - alpha
+  // paste offsets of the input on the canvas (augmentations.py:47)
+  const int px = (canvas_w - T_in) / 2, py = (canvas_h - F_in) / 2;
+
+  // source-column window of this slab (crop coordinates), align_corners=True
+  const float sx = T_out > 1 ? (float)(cw - 1) / (float)(T_out - 1) : 0.f;
+  const float sy = F_out > 1 ? (float)(ch - 1) / (float)(F_out - 1) : 0.f;
+  const int xlo = max(0, (int)floorf(sx * (float)t0) - 1);
+  const int xhi = min(cw - 1, (int)floorf(sx * (float)(t0 + nt - 1)) + 2);
+  const int wt = xhi - xlo + 1;  // host guarantees wt <= LDS_W via TT
+
+  // ---- stage 1: mixed source tile [ch x wt]
+  for (int idx = threadIdx.x; idx < ch * wt; idx += 256) {
+    const int yy = idx / wt, xx = idx - yy * wt;
+    const int r = ci + yy - py, cc = cj + xlo + xx - px;  // input coordinates
+    float v = 0.f;
+    if (r >= 0 && r < F_in && cc >= 0 && cc < T_in) {
+      v = x[(int64_t)r * T_in + cc];
+      if (z) v = logf(wa * expf(v) + wb * expf(z[(int64_t)r * T_in + cc]) + kEps32);
+    }
+    tile[yy * LDS_W + xx] = v;
+  }
+  __syncthreads();
+
+  // ---- stage 2: bicubic + fade
+  const float fade_step = T_out > 1 ? (pr.tail - pr.head) / (float)(T_out - 1) : 0.f;
+  float* o = out + (int64_t)view * F_out * T_out;
+  for (int idx = threadIdx.x; idx < F_out * nt; idx += 256) {
+    const int fy = idx / nt, tx = idx - fy * nt;
+    const int t = t0 + tx;
+    const float rx = sx * (float)t, ry = sy * (float)fy;
+    const float fx = floorf(rx), fyf = floorf(ry);
+    float wx[4], wy[4];
+    cubic_w(rx - fx, wx);
+    cubic_w(ry - fyf, wy);
+    const int ix = (int)fx, iy = (int)fyf;
+    int cx[4], cy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cx[k] = min(max(ix - 1 + k, 0), cw - 1) - xlo;  // taps clamp to the CROP bounds (PyTorch border rule)
+      cy[k] = min(max(iy - 1 + k, 0), ch - 1);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float* row = tile + cy[a] * LDS_W;
+      const float r = row[cx[0]] * wx[0] + row[cx[1]] * wx[1] + row[cx[2]] * wx[2] + row[cx[3]] * wx[3];
+      acc += r * wy[a];
+    }
+    if (do_fade) {
+      // torch.linspace: first half counts up from head, second half counts down from tail
+      const int half = T_out / 2;
+      acc += (t < half) ? pr.head + fade_step * (float)t : pr.tail - fade_step * (float)(T_out - 1 - t);
+    }
+    o[(int64_t)fy * T_out + t] = acc;
+  }
+}
+
+// ---- NormalizeBatch: (X - mean) / clamp(std_unbiased, eps) over the whole [B,1,F,T] tensor
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float shift, double* __restrict__ acc) {
+  __shared__ float red[4];
+  float s = 0.f, q = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - shift;
+    s += d;
+    q += d * d;
+  }
+  s = block_sum_256(s, red);
+  q = block_sum_256(q, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc, (double)s);
+    atomicAdd(acc + 1, (double)q);
+  }
+}
+
+__global__ void normalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float shift, const double* __restrict__ acc,
+                                       float eps) {
+  const double s = acc[0], q = acc[1];
+  const double mean_d = s / (double)n;
+  const double var = (q - s * mean_d) / (double)(n - 1);
+  const float mean = (float)mean_d + shift;
+  const float stdv = fmaxf((float)sqrt(var > 0.0 ? var : 0.0), eps);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = (x[i] - mean) / stdv;
+}
+
+// ---- patch layout for the patch-embed GEMM: [S,1,F,T] fp32 -> bf16 [S * gh * gw, ph * pw], k = i * pw + j
+// (conv weight [d,1,ph,pw] flattened; patch order h-major as conv output .flatten(2), models/mae.py:42)
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int S, int F, int T, int ph, int pw, int gh, int gw) {
+  const int64_t n = (int64_t)S * gh * gw * ph * pw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx;
+    const int j = (int)(r % pw); r /= pw;
+    const int i = (int)(r % ph); r /= ph;
+    const int gx = (int)(r % gw); r /= gw;
+    const int gy = (int)(r % gh); r /= gh;
+    const int s = (int)r;
+    out[idx] = f2bf(img[((int64_t)s * F + gy * ph + i) * T + gx * pw + j]);
+  }
+}
+
+}  // namespace
+
+extern "C" int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_slot, const int32_t* mix_slot, const float* params,
+                                float* out, int32_t n_views, int32_t F_in, int32_t T_in, int32_t canvas_h, int32_t canvas_w, int32_t F_out,
+                                int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream) {
+  SA_CHECK_ARG(lms && src_slot && params && out && n_views > 0, "sa_augment_views: bad args");
+  SA_CHECK_ARG(canvas_h <= LDS_H, "sa_augment_views: canvas height %d exceeds the %d-row LDS tile", canvas_h, LDS_H);
+  SA_CHECK_ARG(F_out > 0 && T_out > 0 && F_in > 0 && T_in > 0 && max_w_ratio > 0.f, "sa_augment_views: bad sizes");
+  // slab width so that ceil(TT * ratio) + 4 source columns fit the LDS tile; ratio = max crop width / T_out
+  int TT = (int)floorf((float)(LDS_W - 5) / max_w_ratio);
+  if (TT > 64) TT = 64;
+  SA_CHECK_ARG(TT >= 1, "sa_augment_views: crop/out width ratio %f too large", max_w_ratio);
+  dim3 grid((T_out + TT - 1) / TT, n_views);
+  hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, (hipStream_t)stream, lms, clip_stride, src_slot, mix_slot,
+                     reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade);
+  SA_LAUNCH_CHECK("sa_augment_views");
+  return 0;
+}
+
+extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream) {
+  SA_CHECK_ARG(x && y && workspace2 && n > 1, "sa_normalize_batch: bad args");
+  if (hipMemsetAsync(workspace2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) {
+    sa_set_error("sa_normalize_batch: memset failed");
+    return 2;
+  }
+  int64_t want = (n + 256 * 16 - 1) / (256 * 16);
+  const int grid = (int)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, shift, workspace2);
+  hipLaunchKernelGGL(normalize_apply_kernel, dim3(grid * 4), dim3(256), 0, (hipStream_t)stream, x, y, n, shift, workspace2, eps);
+  SA_LAUNCH_CHECK("sa_normalize_batch");
+  return 0;
+}
+
+extern "C" int sa_patchify_bf16(const float* img, void* out, int32_t S, int32_t F, int32_t T, int32_t ph, int32_t pw, void* stream) {
+  SA_CHECK_ARG(img && out && S > 0 && F >= ph && T >= pw && ph > 0 && pw > 0, "sa_patchify_bf16: bad args");
+  const int gh = F / ph, gw = T / pw;
+  const int64_t n = (int64_t)S * gh * gw * ph * pw;
+  int64_t want = (n + 255) / 256;
+  const int grid = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, S, F, T, ph, pw, gh, gw);
+  SA_LAUNCH_CHECK("sa_patchify_bf16");
+  return 0;
+}

@@ -1,0 +1,267 @@
+// BatchNorm1d (train mode) pieces + the Barlow Twins loss, fp32 throughout.
+//
+// The projector / predictor BN (model.py:20,42) and the loss's affine-less BN (utils/loss.py:13,17) are
+// split into  column statistics -> [cross-rank combine by the host side] -> apply, so that the same
+// kernels serve one GPU and the global-batch-exact data-parallel path.
+// The cross-correlation c = z1n^T z2n / B (utils/loss.py:17-19) and the two backward products run on the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): 16.8 MFLOP at B=128, D=256 -- latency, not throughput.
+#include "common.h"
+#include "../../include/ssl_audio_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+// ---- per-column mean and M2 = sum (x - mean)^2 over the local rows (two-pass, one thread per column)
+__global__ void bn_colstats_kernel(const float* __restrict__ x, int64_t ld, int B, int C, float* __restrict__ mean_out,
+                                   float* __restrict__ m2_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += x[(int64_t)b * ld + c];
+  const float mean = s / (float)B;
+  float q = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = x[(int64_t)b * ld + c] - mean;
+    q += d * d;
+  }
+  mean_out[c] = mean;
+  m2_out[c] = q;
+}
+
+// ---- y = (x - mean) * rstd [* gamma + beta] [relu]; rstd = rsqrt(var + eps) is given
+__global__ void bn_apply_kernel(const float* __restrict__ x, int64_t ld, int B, int C, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                int relu, float* __restrict__ y_f32, bf16_t* __restrict__ y_bf16, int64_t ldy) {
+  const int64_t n = (int64_t)B * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / C), c = (int)(i % C);
+    float v = (x[(int64_t)b * ld + c] - mean[c]) * rstd[c];
+    if (gamma) v = v * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    if (y_f32) y_f32[(int64_t)b * ldy + c] = v;
+    if (y_bf16) y_bf16[(int64_t)b * ldy + c] = f2bf(v);
+  }
+}
+
+// ---- backward column sums: s1 = sum_b g, s2 = sum_b g * xhat, with g = dy * [relu mask] (dy w.r.t. BN output)
+// dgamma = s2, dbeta = s1 (local contributions).
+template <typename DY>
+__global__ void bn_bwd_stats_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ld, int B, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int relu, float* __restrict__ s1_out, float* __restrict__ s2_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], r = rstd[c];
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float xh = (x[(int64_t)b * ld + c] - mu) * r;
+    float d = (float)dy[(int64_t)b * lddy + c];
+    if (relu && !(xh * g + bt > 0.f)) d = 0.f;
+    s1 += d;
+    s2 += d * xh;
+  }
+  s1_out[c] = s1;
+  s2_out[c] = s2;
+}
+
+// ---- dx = gamma * rstd * (g - s1/N - xhat * s2/N), N = global row count, s1/s2 already summed over ranks
+template <typename DY>
+__global__ void bn_bwd_apply_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ld, int B, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int relu, const float* __restrict__ s1, const float* __restrict__ s2,
+                                    float inv_n, float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx) {
+  const int64_t n = (int64_t)B * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / C), c = (int)(i % C);
+    const float r = rstd[c];
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float xh = (x[(int64_t)b * ld + c] - mean[c]) * r;
+    float d = (float)dy[(int64_t)b * lddy + c];
+    if (relu && !(xh * g + bt > 0.f)) d = 0.f;
+    const float o = g * r * (d - s1[c] * inv_n - xh * s2[c] * inv_n);
+    if (dx_f32) dx_f32[(int64_t)b * lddx + c] = o;
+    if (dx_bf16) dx_bf16[(int64_t)b * lddx + c] = f2bf(o);
+  }
+}
+
+// ---- small exact-fp32 matmul on v_mfma_f32_32x32x2_f32: C[m][n] = alpha * sum_k A(m,k) * B(k,n)
+// A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]  (general strides cover every transpose the loss needs).
+// One wave per 32x32 output tile.  Lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+__global__ __launch_bounds__(64) void matmul_f32_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B,
+                                                        int64_t sbk, int64_t sbn, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                        float alpha) {
+  const int lane = threadIdx.x;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int i = lane & 31, kk = lane >> 5;
+  const bool mv = (m0 + i) < M, nv = (n0 + i) < N;
+  const float* ap = A + (int64_t)(m0 + i) * sam;
+  const float* bp = B + (int64_t)(n0 + i) * sbn;
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= K; k += 8) {
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kq = k + 2 * u + kk;
+      a[u] = mv ? ap[(int64_t)kq * sak] : 0.f;
+      b[u] = nv ? bp[(int64_t)kq * sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < K; k += 2) {
+    const int kq = k + kk;
+    const float a = (mv && kq < K) ? ap[(int64_t)kq * sak] : 0.f;
+    const float b = (nv && kq < K) ? bp[(int64_t)kq * sbk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int n = n0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < M && n < N) C[(int64_t)m * ldc + n] = alpha * acc[r];
+  }
+}
+
+// ---- loss = alpha * sum_i (c_ii - 1)^2 + lambda * sum_{i != j} (c_ij [+1])^2 ; G = dL/dc   (utils/loss.py:23-30)
+__global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restrict__ c, int D, float alpha, float lambda, int hsic,
+                                                           float* __restrict__ loss, float* __restrict__ G) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int n = D * D;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int i = idx / D, j = idx % D;
+    const float v = c[idx];
+    float g, t;
+    if (i == j) {
+      t = v - 1.f;
+      s += alpha * t * t;
+      g = 2.f * alpha * t;
+    } else {
+      t = hsic ? v + 1.f : v;
+      s += lambda * t * t;
+      g = 2.f * lambda * t;
+    }
+    if (G) G[idx] = g;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s);
+}
+
+// ---- flat elementwise: AdamW (torch.optim.AdamW semantics, decoupled decay), EMA, scaled add
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             float lr, float b1, float b2, float eps, float wd, float inv_c1, float inv_sqrt_c2, float grad_scale,
+                             bf16_t* __restrict__ p_bf16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_c2 + eps;
+    pi -= lr * inv_c1 * mi / denom;
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    tgt[i] = tgt[i] * beta + (1.f - beta) * src[i];
+}
+
+inline int flat_grid(int64_t n, int per_thread = 1) {
+  const int64_t want = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+  return (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
+}
+
+}  // namespace
+
+extern "C" int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, float* mean, float* m2, void* stream) {
+  SA_CHECK_ARG(x && mean && m2 && B > 0 && C > 0, "sa_bn_colstats: bad args");
+  hipLaunchKernelGGL(bn_colstats_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, ld, B, C, mean, m2);
+  SA_LAUNCH_CHECK("sa_bn_colstats");
+  return 0;
+}
+
+extern "C" int sa_bn_apply(const float* x, int64_t ld, int32_t B, int32_t C, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int32_t relu, float* y_f32, void* y_bf16, int64_t ldy, void* stream) {
+  SA_CHECK_ARG(x && mean && rstd && (y_f32 || y_bf16) && B > 0 && C > 0, "sa_bn_apply: bad args");
+  SA_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "sa_bn_apply: gamma and beta must be given together");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(flat_grid((int64_t)B * C)), dim3(256), 0, (hipStream_t)stream, x, ld, B, C, mean, rstd, gamma, beta,
+                     relu, y_f32, (bf16_t*)y_bf16, ldy);
+  SA_LAUNCH_CHECK("sa_bn_apply");
+  return 0;
+}
+
+extern "C" int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, float* s1,
+                               float* s2, void* stream) {
+  SA_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && B > 0 && C > 0, "sa_bn_bwd_stats: bad args");
+  if (dy_is_bf16)
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<bf16_t>), dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, x, ld, B,
+                       C, mean, rstd, gamma, beta, relu, s1, s2);
+  else
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<float>), dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)dy, lddy, x, ld, B, C,
+                       mean, rstd, gamma, beta, relu, s1, s2);
+  SA_LAUNCH_CHECK("sa_bn_bwd_stats");
+  return 0;
+}
+
+extern "C" int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* s1,
+                               const float* s2, float inv_n, float* dx_f32, void* dx_bf16, int64_t lddx, void* stream) {
+  SA_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (dx_f32 || dx_bf16) && B > 0 && C > 0, "sa_bn_bwd_apply: bad args");
+  const int grid = flat_grid((int64_t)B * C);
+  if (dy_is_bf16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, x, ld, B, C, mean,
+                       rstd, gamma, beta, relu, s1, s2, inv_n, dx_f32, (bf16_t*)dx_bf16, lddx);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, x, ld, B, C, mean,
+                       rstd, gamma, beta, relu, s1, s2, inv_n, dx_f32, (bf16_t*)dx_bf16, lddx);
+  SA_LAUNCH_CHECK("sa_bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
+                             int32_t M, int32_t N, int32_t K, float alpha, void* stream) {
+  SA_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "sa_matmul_f32: bad args");
+  hipLaunchKernelGGL(matmul_f32_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(64), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc,
+                     M, N, K, alpha);
+  SA_LAUNCH_CHECK("sa_matmul_f32");
+  return 0;
+}
+
+extern "C" int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream) {
+  SA_CHECK_ARG(c && loss && D > 0, "sa_bt_loss_grad: bad args");
+  if (hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    sa_set_error("sa_bt_loss_grad: memset failed");
+    return 2;
+  }
+  int grid = (D * D + 255) / 256;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(bt_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c, D, alpha, lambda, hsic, loss, G);
+  SA_LAUNCH_CHECK("sa_bt_loss_grad");
+  return 0;
+}
+
+extern "C" int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream) {
+  SA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "sa_adamw_step: bad args");
+  if (n == 0) return 0;
+  const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale, (bf16_t*)p_bf16);
+  SA_LAUNCH_CHECK("sa_adamw_step");
+  return 0;
+}
+
+extern "C" int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream) {
+  SA_CHECK_ARG(target && online && n >= 0, "sa_ema_update: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta);
+  SA_LAUNCH_CHECK("sa_ema_update");
+  return 0;
+}

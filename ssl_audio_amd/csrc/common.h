@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of ssl_audio_amd.
+// wave = 64 lanes everywhere; no other architecture is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SA_WAVE 64
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- error plumbing shared by all C-ABI entry points (capi.cpp owns the storage)
+extern "C" void sa_set_error(const char* fmt, ...);
+#define SA_CHECK_ARG(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      sa_set_error(__VA_ARGS__);                \
+      return 1;                                 \
+    }                                           \
+  } while (0)
+#define SA_LAUNCH_CHECK(name)                                                  \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      sa_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+      return 2;                                                                \
+    }                                                                          \
+  } while (0)
+
+// ---- wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- bf16 helpers (plain casts: hipcc emits v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserving)
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+
+// exact-erf GELU (timm Mlp act_layer=nn.GELU, models/mae.py:155) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0 (used for ragged tiles)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}

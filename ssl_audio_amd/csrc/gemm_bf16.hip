@@ -1,0 +1,375 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues (bias / GELU / GELU' / residual / row scatter / split-K).
+//
+// Tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles
+// (64 accumulator VGPRs).  Both operand tiles are brought HBM -> LDS by `buffer_load_dwordx4 ... lds`
+// (no VGPR round trip, hardware bounds check gives zero fill for ragged M / N / K-rows), two LDS
+// buffers, one barrier per K step.  Each operand can be stored with the reduction index contiguous
+// ("k-major": 128-byte LDS rows, XOR-swizzled 16-byte chunks, ds_read_b128 fragments) or strided
+// ("k-strided": 256-byte LDS rows, ds_read_b64_tr_b16 transposing reads), so forward (NT), dgrad (NN)
+// and wgrad (TN) are the same kernel and no transposed copy of a weight or activation is ever made.
+// LDS destination of an LDS-DMA is lane-linear, so swizzles are applied to the per-lane SOURCE address
+// and again on the fragment read (cdna_hip_programming.md rule 21).
+#include "common.h"
+#include "../../include/ssl_audio_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+  const char* A; const char* B;
+  uint32_t a_bytes, b_bytes;       // buffer extents for the hardware bounds check
+  int lda, ldb;
+  int M, N, K;
+  float alpha;
+  const float* bias;
+  int act;
+  const bf16_t* aux_in; bf16_t* aux_out; int64_t ldaux;
+  const float* residual; int64_t ldr; int res_mod;
+  float* out_f32; int64_t ldo_f32;
+  bf16_t* out_bf16; int64_t ldo_bf16;
+  int row_group;
+  int split_k; int accumulate;
+  int tiles_m, tiles_n;
+};
+
+// 16-byte-chunk XOR for a k-strided tile row: rows {0..3, 8..11} (one 32-lane half of a transposing
+// read) land on 8 distinct 32-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+
+// ---- HBM -> LDS staging of one operand tile ---------------------------------------------------------
+// k-major operand: tile = 128 rows x 64 k (128 B rows).  16 wave-instructions of 1 KiB (8 rows each).
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
+                                           int wave, int lane) {
+  if constexpr (KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = wave * 4 + i;
+      const int row = q * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (row & 7);
+      const uint32_t voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+    }
+  } else {
+    // k-strided operand: tile = 64 k-rows x 128 cols (256 B rows).  16 wave-instructions (4 k-rows each).
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = wave * 4 + i;
+      const int krow = q * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ ks_swz(krow);
+      const uint32_t voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+}
+
+// ---- LDS -> register fragment for one 16-wide sub-tile and one 32-deep k-step -------------------------
+// Returns the 8 bf16 a lane feeds to v_mfma_f32_16x16x32_bf16: element j <-> k = 8*(lane>>4) + j, for
+// output index (row of A / column of B) sub0 + (lane & 15).
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int sub0, int kstep, int lane) {
+  if constexpr (KMAJOR) {
+    const int r = sub0 + (lane & 15);
+    const int kq = kstep * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((kq ^ (r & 7)) << 4));
+  } else {
+    const int i = lane & 15, g = lane >> 4;
+    const int krow = kstep * 32 + 8 * g + (i >> 2);
+    const int col = sub0 + 4 * (i & 3);
+    const int off = (((col >> 3) ^ ks_swz(krow)) << 4) + ((col >> 2) & 1) * 8;  // ks_swz(krow) == ks_swz(krow + 4)
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + krow * 256 + off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + (krow + 4) * 256 + off));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware, bijective remap: the 8 XCDs are dealt blocks round-robin; give each a contiguous run of
+  // logical ids so neighbouring tiles (same A row-panel, adjacent B panels) share one L2.
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ks_id = lid % p.split_k;
+  const int tile = lid / p.split_k;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int ksteps = (p.K + BK - 1) / BK;
+  const int chunk = (ksteps + p.split_k - 1) / p.split_k;
+  const int kt_begin = ks_id * chunk;
+  const int kt_end = min(ksteps, kt_begin + chunk);
+  if (kt_begin >= kt_end) return;  // (only possible for split_k > 1: nothing to add)
+
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS layout: [buffer 0: A tile | B tile][buffer 1: A tile | B tile]
+  stage_tile<A_KM>(ra, smem, p.lda, m0, kt_begin * BK, wave, lane);
+  stage_tile<B_KM>(rb, smem + TILE_BYTES, p.ldb, n0, kt_begin * BK, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) {
+      char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile<A_KM>(ra, nxt, p.lda, m0, (kt + 1) * BK, wave, lane);
+      stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0, (kt + 1) * BK, wave, lane);
+    }
+    const char* ta = smem + cur * 2 * TILE_BYTES;
+    const char* tb = ta + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KM>(ta, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (SWAP)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int g = lane >> 4, c = lane & 15;
+  if constexpr (!SWAP) {
+    // split-K: lane owns rows m = 4g + r of one column n -> 16 consecutive dwords per row per instruction
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
+          if (m < p.M && n < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+        }
+      }
+  } else {
+    // lane owns one row m and 4 consecutive columns n..n+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + c;
+      if (m >= p.M) continue;
+      const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+      const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + 4 * g;
+        if (n >= p.N) continue;
+        float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+        const bool full = (n + 3 < p.N);
+        if (full) {
+          if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+          if (p.act == 1) {
+            if (p.aux_out) {
+              bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+              *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+          } else if (p.act == 2) {
+            const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+          }
+          if (p.residual) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          if (p.out_f32) {
+            float* o = p.out_f32 + orow * p.ldo_f32 + n;
+            if (p.accumulate) {
+              const float4 old = *reinterpret_cast<const float4*>(o);
+              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+            }
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+          if (p.out_bf16) {
+            bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(p.out_bf16 + orow * p.ldo_bf16 + n) = h;
+          }
+        } else {
+          for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r];
+            if (p.bias) x += p.bias[n + r];
+            if (p.act == 1) {
+              if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
+              x = gelu_f(x);
+            } else if (p.act == 2) {
+              x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
+            }
+            if (p.residual) x += p.residual[rrow * p.ldr + n + r];
+            if (p.out_f32) {
+              float* o = p.out_f32 + orow * p.ldo_f32 + n + r;
+              *o = p.accumulate ? *o + x : x;
+            }
+            if (p.out_bf16) p.out_bf16[orow * p.ldo_bf16 + n + r] = f2bf(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool A_KM, bool B_KM, bool SWAP>
+int launch(const GemmParams& p, hipStream_t stream) {
+  const int nwg = p.tiles_m * p.tiles_n * p.split_k;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<A_KM, B_KM, SWAP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<A_KM, B_KM, SWAP>), dim3(nwg), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16");
+  return 0;
+}
+
+// ---------------------------------------------------------------- small helpers
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(src + i);
+      const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+      bf16x8 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w), f2bf(b.x), f2bf(b.y), f2bf(b.z), f2bf(b.w)};
+      *reinterpret_cast<bf16x8*>(dst + i) = o;
+    } else {
+      for (int64_t k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+    }
+  }
+}
+
+// column sums: block handles 64 columns x a slab of rows; 256 threads = 4 row-phases x 64 columns
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + ph; r < r1; r += 4) s += bf2f(x[(int64_t)r * ld + col]);
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SA_CHECK_ARG(a != nullptr, "sa_gemm_bf16: null args");
+  SA_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "sa_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  SA_CHECK_ARG(a->A && a->B, "sa_gemm_bf16: null operand");
+  SA_CHECK_ARG(a->out_f32 || a->out_bf16, "sa_gemm_bf16: no output");
+  SA_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0, "sa_gemm_bf16: lda/ldb must be multiples of 8 elements (16-byte rows)");
+  SA_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "sa_gemm_bf16: operands must be 16-byte aligned");
+  if (a->a_kmajor || a->b_kmajor)
+    SA_CHECK_ARG(a->K % BK == 0, "sa_gemm_bf16: K=%d must be a multiple of %d when an operand is k-major", a->K, BK);
+  SA_CHECK_ARG(a->split_k >= 1, "sa_gemm_bf16: split_k must be >= 1");
+  if (a->split_k > 1)
+    SA_CHECK_ARG(a->out_f32 && !a->out_bf16 && !a->bias && !a->act && !a->residual && !a->row_group,
+                 "sa_gemm_bf16: split_k > 1 supports only alpha and fp32 atomic accumulation");
+  if (a->act == 2) SA_CHECK_ARG(a->aux_in != nullptr, "sa_gemm_bf16: act=2 needs aux_in");
+  if (a->out_f32) SA_CHECK_ARG(a->ldo_f32 % 4 == 0 && ((uintptr_t)a->out_f32 & 15) == 0, "sa_gemm_bf16: fp32 output must be 16-byte aligned rows");
+  if (a->out_bf16) SA_CHECK_ARG(a->ldo_bf16 % 4 == 0 && ((uintptr_t)a->out_bf16 & 7) == 0, "sa_gemm_bf16: bf16 output rows must be 8-byte aligned");
+  if (a->residual) SA_CHECK_ARG(a->ldr % 4 == 0 && ((uintptr_t)a->residual & 15) == 0, "sa_gemm_bf16: residual must be 16-byte aligned rows");
+  if (a->bias) SA_CHECK_ARG(((uintptr_t)a->bias & 15) == 0, "sa_gemm_bf16: bias must be 16-byte aligned");
+  if (a->aux_in || a->aux_out) SA_CHECK_ARG(a->ldaux % 4 == 0, "sa_gemm_bf16: ldaux must be a multiple of 4");
+
+  GemmParams p;
+  p.A = (const char*)a->A; p.B = (const char*)a->B;
+  // extents in bytes: last row only spans its valid elements, so anything past it is out of range (zero fill)
+  const int64_t a_rows = a->a_kmajor ? a->M : a->K, a_cols = a->a_kmajor ? a->K : a->M;
+  const int64_t b_rows = a->b_kmajor ? a->N : a->K, b_cols = a->b_kmajor ? a->K : a->N;
+  const int64_t a_bytes = ((a_rows - 1) * a->lda + a_cols) * 2, b_bytes = ((b_rows - 1) * a->ldb + b_cols) * 2;
+  const int64_t lim = (int64_t)1 << 32;
+  SA_CHECK_ARG((a_rows + 2 * BM) * a->lda * 2 < lim && (b_rows + 2 * BM) * a->ldb * 2 < lim,
+               "sa_gemm_bf16: operand larger than the 4 GiB buffer-descriptor range");
+  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.lda = (int)a->lda; p.ldb = (int)a->ldb;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.alpha = a->alpha;
+  p.bias = a->bias; p.act = a->act;
+  p.aux_in = (const bf16_t*)a->aux_in; p.aux_out = (bf16_t*)a->aux_out; p.ldaux = a->ldaux;
+  p.residual = a->residual; p.ldr = a->ldr; p.res_mod = a->res_mod;
+  p.out_f32 = a->out_f32; p.ldo_f32 = a->ldo_f32;
+  p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
+  p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
+  p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
+
+  const bool swap = a->split_k == 1;
+  const int sel = (a->a_kmajor ? 4 : 0) | (a->b_kmajor ? 2 : 0) | (swap ? 1 : 0);
+  switch (sel) {
+    case 7: return launch<true, true, true>(p, stream);
+    case 6: return launch<true, true, false>(p, stream);
+    case 5: return launch<true, false, true>(p, stream);
+    case 4: return launch<true, false, false>(p, stream);
+    case 3: return launch<false, true, true>(p, stream);
+    case 2: return launch<false, true, false>(p, stream);
+    case 1: return launch<false, false, true>(p, stream);
+    default: return launch<false, false, false>(p, stream);
+  }
+}
+
+extern "C" int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  SA_CHECK_ARG(n >= 0 && (n == 0 || (src && dst)), "sa_cast_f32_to_bf16: bad args");
+  if (n == 0) return 0;
+  SA_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "sa_cast_f32_to_bf16: pointers must be 16-byte aligned");
+  const int64_t want = (n + 8 * 256 - 1) / (8 * 256);
+  const int grid = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  SA_LAUNCH_CHECK("sa_cast_f32_to_bf16");
+  return 0;
+}
+
+extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream) {
+  SA_CHECK_ARG(x && out && M > 0 && N > 0, "sa_colsum_bf16: bad args");
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream) != hipSuccess) {
+      sa_set_error("sa_colsum_bf16: memset failed");
+      return 2;
+    }
+  }
+  const int gx = (N + 63) / 64;
+  int gy = (2048 + gx - 1) / gx;
+  const int max_gy = (M + 63) / 64;
+  if (gy > max_gy) gy = max_gy;
+  const int rows_per_block = (M + gy - 1) / gy;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block);
+  SA_LAUNCH_CHECK("sa_colsum_bf16");
+  return 0;
+}

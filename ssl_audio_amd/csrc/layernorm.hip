@@ -1,0 +1,198 @@
+// LayerNorm forward / backward for the ViT residual stream (fp32 stream, bf16 GEMM operands).
+// HBM-bound: one wave per row, the row lives in registers (D <= 2048), 16-byte loads, wave reductions.
+// Replaces nn.LayerNorm(eps=1e-6) at models/mae.py:149,153,208 (+ decoder_norm :227).
+#include "common.h"
+#include "../../include/ssl_audio_hip.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane -> D <= 64 * 4 * 8 = 2048
+
+// y = (x - mean) * rstd * gamma + beta ; writes bf16 and/or fp32, saves mean / rstd per row
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y_bf16,
+                                                     float* __restrict__ y_f32, int64_t ldy, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nv = D >> 2;  // float4 per row
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        v[i] = xr[c];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 b = reinterpret_cast<const float4*>(beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + b.x;
+        o.y = (v[i].y - mean) * rstd * g.y + b.y;
+        o.z = (v[i].z - mean) * rstd * g.z + b.z;
+        o.w = (v[i].w - mean) * rstd * g.w + b.w;
+        if (y_f32) reinterpret_cast<float4*>(y_f32 + (int64_t)row * ldy)[c] = o;
+        if (y_bf16) {
+          bf16x4 h = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+          reinterpret_cast<bf16x4*>(y_bf16 + (int64_t)row * ldy)[c] = h;
+        }
+      }
+    }
+  }
+}
+
+// dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy
+// dy arrives as bf16 (from a dgrad GEMM) or fp32 (from the loss side).  Each lane owns fixed columns, so its
+// dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + atomics at the end.
+template <typename DY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
+                                                     float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+  __shared__ float red[4 * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  float4 ag[MAXV], ab[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+    float4 xh[MAXV], gd[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 xv = xr[c];
+        float4 d;
+        if constexpr (sizeof(DY) == 2) {
+          const bf16x4 h = reinterpret_cast<const bf16x4*>(dy + (int64_t)row * lddy)[c];
+          d = make_float4(bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3]));
+        } else {
+          d = reinterpret_cast<const float4*>(dy + (int64_t)row * lddy)[c];
+        }
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 o;
+        o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
+        o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
+        o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
+        o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
+        if (dres) {
+          const float4 r = reinterpret_cast<const float4*>(dres + (int64_t)row * lddres)[c];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (dx_f32) reinterpret_cast<float4*>(dx_f32 + (int64_t)row * lddx)[c] = o;
+        if (dx_bf16) {
+          bf16x4 h = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+          reinterpret_cast<bf16x4*>(dx_bf16 + (int64_t)row * lddx)[c] = h;
+        }
+      }
+    }
+  }
+  if (dgamma == nullptr && dbeta == nullptr) return;
+  // cross-wave reduce of the per-lane column partials, then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (i * 64 >= nv) break;
+    __syncthreads();
+    reinterpret_cast<float4*>(red)[wave * 64 + lane] = ag[i];
+    __syncthreads();
+    if (wave == 0 && c < nv && dgamma) {
+      float4 t = reinterpret_cast<float4*>(red)[lane];
+      for (int w = 1; w < 4; ++w) {
+        const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      atomicAdd(dgamma + 4 * c + 0, t.x); atomicAdd(dgamma + 4 * c + 1, t.y);
+      atomicAdd(dgamma + 4 * c + 2, t.z); atomicAdd(dgamma + 4 * c + 3, t.w);
+    }
+    __syncthreads();
+    reinterpret_cast<float4*>(red)[wave * 64 + lane] = ab[i];
+    __syncthreads();
+    if (wave == 0 && c < nv && dbeta) {
+      float4 t = reinterpret_cast<float4*>(red)[lane];
+      for (int w = 1; w < 4; ++w) {
+        const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      atomicAdd(dbeta + 4 * c + 0, t.x); atomicAdd(dbeta + 4 * c + 1, t.y);
+      atomicAdd(dbeta + 4 * c + 2, t.z); atomicAdd(dbeta + 4 * c + 3, t.w);
+    }
+  }
+}
+
+inline int ln_grid(int M) {
+  const int want = (M + 3) / 4;
+  return want < 2048 ? want : 2048;
+}
+
+}  // namespace
+
+extern "C" int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, float eps, void* stream) {
+  SA_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "sa_layernorm_fwd: null pointer");
+  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "sa_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV);
+  SA_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "sa_layernorm_fwd: leading dims must be multiples of 4");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16_t*)y_bf16, y_f32, ldy,
+                     mean, rstd, M, D, eps);
+  SA_LAUNCH_CHECK("sa_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
+                                int64_t lddx, float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
+  SA_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "sa_layernorm_bwd: null pointer");
+  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "sa_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV);
+  SA_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "sa_layernorm_bwd: leading dims must be multiples of 4");
+  // fewer, fatter blocks than forward: every block ends with 2*D atomics
+  int grid = (M + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  if (dy_is_bf16)
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, x, ldx, gamma, mean,
+                       rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, gamma, mean,
+                       rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D);
+  SA_LAUNCH_CHECK("sa_layernorm_bwd");
+  return 0;
+}

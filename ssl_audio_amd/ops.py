@@ -1,0 +1,241 @@
+"""Thin torch-tensor wrappers over the C ABI (include/ssl_audio_hip.h).
+
+PyTorch is used for device memory, streams and (elsewhere) torch.distributed only; every arithmetic op on the
+hot path goes through libssl_audio_hip.so.  All calls are enqueued on torch's current HIP stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SaGemmArgs, check, lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (ssl_audio_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _rows(t, name):
+    """2-D row-major view info: (rows, cols, leading dim)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
+         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False):
+    """D = epilogue(alpha * A.B).  A: [M,K] (a_kmajor) or [K,M]; B: [N,K] (b_kmajor, nn.Linear weight) or [K,N]."""
+    _req(A, BF16, "A"), _req(B, BF16, "B")
+    ar, ac, lda = _rows(A, "A")
+    br, bc, ldb = _rows(B, "B")
+    M, K = (ar, ac) if a_kmajor else (ac, ar)
+    N, Kb = (br, bc) if b_kmajor else (bc, br)
+    if K != Kb:
+        raise ValueError(f"gemm: inner dims differ ({K} vs {Kb})")
+    a = SaGemmArgs()
+    a.A, a.lda, a.a_kmajor = A.data_ptr(), lda, int(a_kmajor)
+    a.B, a.ldb, a.b_kmajor = B.data_ptr(), ldb, int(b_kmajor)
+    a.M, a.N, a.K, a.alpha = M, N, K, float(alpha)
+    a.bias = _req(bias, F32, "bias").data_ptr() if bias is not None else None
+    a.act = act
+    if aux_in is not None:
+        a.aux_in, a.ldaux = _req(aux_in, BF16, "aux_in").data_ptr(), _rows(aux_in, "aux_in")[2]
+    if aux_out is not None:
+        a.aux_out, a.ldaux = _req(aux_out, BF16, "aux_out").data_ptr(), _rows(aux_out, "aux_out")[2]
+    if residual is not None:
+        a.residual, a.ldr = _req(residual, F32, "residual").data_ptr(), _rows(residual, "residual")[2]
+    a.res_mod = res_mod
+    if out_f32 is not None:
+        a.out_f32, a.ldo_f32 = _req(out_f32, F32, "out_f32").data_ptr(), _rows(out_f32, "out_f32")[2]
+    if out_bf16 is not None:
+        a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
+    a.row_group, a.split_k, a.accumulate = row_group, split_k, int(accumulate)
+    check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
+
+
+def pick_split_k(M, N, K, cu_count=256):
+    """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ksteps = (K + 63) // 64
+    split = 1
+    while tiles * split < 2 * cu_count and split * 2 <= ksteps // 4:
+        split *= 2
+    return split
+
+
+def cast_bf16(src, dst=None):
+    _req(src, F32, "src")
+    src = src.contiguous()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib().sa_cast_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "sa_cast_f32_to_bf16")
+    return dst
+
+
+def colsum_bf16(x, out, accumulate=False):
+    M, N, ld = _rows(_req(x, BF16, "x"), "x")
+    check(lib().sa_colsum_bf16(_p(x), ld, M, N, _p(_req(out, F32, "out")), int(accumulate), _stream()), "sa_colsum_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rstd=None):
+    M, D, ldx = _rows(_req(x, F32, "x"), "x")
+    y = y_bf16 if y_bf16 is not None else y_f32
+    ldy = _rows(y, "y")[2]
+    if y_bf16 is not None and y_f32 is not None and _rows(y_f32, "y_f32")[2] != ldy:
+        raise ValueError("layernorm_fwd: both outputs must share a leading dimension")
+    check(lib().sa_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), ldy, _p(mean), _p(rstd), M, D, float(eps),
+                                 _stream()), "sa_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None):
+    M, D, ldx = _rows(_req(x, F32, "x"), "x")
+    lddy = _rows(dy, "dy")[2]
+    dxo = dx_f32 if dx_f32 is not None else dx_bf16
+    lddx = _rows(dxo, "dx")[2]
+    lddres = _rows(dres, "dres")[2] if dres is not None else 0
+    check(lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
+                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), M, D, _stream()), "sa_layernorm_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv, H, N, scale, out, lse=None):
+    rows, w, ld = _rows(_req(qkv, BF16, "qkv"), "qkv")
+    Cdim = w // 3
+    check(lib().sa_attention_fwd(_p(qkv), rows, ld, Cdim, H, N, float(scale), _p(_req(out, BF16, "out")), _rows(out, "out")[2],
+                                 _p(lse), _stream()), "sa_attention_fwd")
+
+
+def attention_bwd(qkv, H, N, scale, out, dout, lse, dqkv):
+    rows, w, ld = _rows(_req(qkv, BF16, "qkv"), "qkv")
+    Cdim = w // 3
+    if _rows(dqkv, "dqkv")[2] != ld or _rows(dout, "dout")[2] != _rows(out, "out")[2]:
+        raise ValueError("attention_bwd: dqkv/qkv and dout/out must share leading dimensions")
+    check(lib().sa_attention_bwd(_p(qkv), rows, ld, Cdim, H, N, float(scale), _p(out), _p(_req(dout, BF16, "dout")), _rows(out, "out")[2],
+                                 _p(_req(lse, F32, "lse")), _p(_req(dqkv, BF16, "dqkv")), _stream()), "sa_attention_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm pieces
+def bn_colstats(x, mean, m2):
+    B, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    check(lib().sa_bn_colstats(_p(x), ld, B, Cn, _p(mean), _p(m2), _stream()), "sa_bn_colstats")
+
+
+def bn_apply(x, mean, rstd, gamma=None, beta=None, relu=False, *, y_f32=None, y_bf16=None):
+    B, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    y = y_f32 if y_f32 is not None else y_bf16
+    check(lib().sa_bn_apply(_p(x), ld, B, Cn, _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(y_f32), _p(y_bf16),
+                            _rows(y, "y")[2], _stream()), "sa_bn_apply")
+
+
+def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s1, s2):
+    B, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    check(lib().sa_bn_bwd_stats(_p(dy), int(dy.dtype == BF16), _rows(dy, "dy")[2], _p(x), ld, B, Cn, _p(mean), _p(rstd), _p(gamma),
+                                _p(beta), int(relu), _p(s1), _p(s2), _stream()), "sa_bn_bwd_stats")
+
+
+def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s1, s2, inv_n, *, dx_f32=None, dx_bf16=None):
+    B, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    dxo = dx_f32 if dx_f32 is not None else dx_bf16
+    check(lib().sa_bn_bwd_apply(_p(dy), int(dy.dtype == BF16), _rows(dy, "dy")[2], _p(x), ld, B, Cn, _p(mean), _p(rstd), _p(gamma),
+                                _p(beta), int(relu), _p(s1), _p(s2), float(inv_n), _p(dx_f32), _p(dx_bf16), _rows(dxo, "dx")[2],
+                                _stream()), "sa_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------------ loss pieces
+def matmul_f32(A, B, out, *, trans_a=False, trans_b=False, alpha=1.0):
+    """out[M,N] = alpha * op(A) @ op(B) in exact fp32 (MFMA f32)."""
+    _req(A, F32, "A"), _req(B, F32, "B"), _req(out, F32, "out")
+    sam, sak = (A.stride(1), A.stride(0)) if trans_a else (A.stride(0), A.stride(1))
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    sbk, sbn = (B.stride(1), B.stride(0)) if trans_b else (B.stride(0), B.stride(1))
+    Kb, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != Kb or tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        raise ValueError("matmul_f32: shape mismatch")
+    check(lib().sa_matmul_f32(_p(A), sam, sak, _p(B), sbk, sbn, _p(out), out.stride(0), M, N, K, float(alpha), _stream()), "sa_matmul_f32")
+    return out
+
+
+def bt_loss_grad(c, alpha, lmbda, hsic, loss, G=None):
+    D = c.shape[0]
+    check(lib().sa_bt_loss_grad(_p(_req(c, F32, "c")), D, float(alpha), float(lmbda), int(bool(hsic)), _p(loss), _p(G), _stream()),
+          "sa_bt_loss_grad")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None):
+    n = p.numel()
+    check(lib().sa_adamw_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                              float(grad_scale), _p(p_bf16), _stream()), "sa_adamw_step")
+
+
+def ema_update(target, online, beta):
+    check(lib().sa_ema_update(_p(target), _p(online), target.numel(), float(beta), _stream()), "sa_ema_update")
+
+
+# ------------------------------------------------------------------------------------------------ frontend / augmentation
+def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop):
+    B, L = wave.shape
+    check(lib().sa_logmel_fwd(_p(_req(wave, F32, "wave")), wave.stride(0), B, L, _p(tables["window"]), _p(tables["twiddle"]),
+                              _p(tables["mel_weights"]), _p(tables["mel_lo"]), _p(tables["mel_len"]), _p(_req(out, F32, "out")),
+                              out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd")
+
+
+def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in, canvas, max_w_ratio, do_fade):
+    V, F_out, T_out = out.shape[0], out.shape[-2], out.shape[-1]
+    check(lib().sa_augment_views(_p(_req(lms, F32, "lms")), clip_stride, _p(src_slot), _p(mix_slot), _p(_req(params, F32, "params")),
+                                 _p(_req(out, F32, "out")), V, F_in, T_in, canvas[0], canvas[1], F_out, T_out, float(max_w_ratio),
+                                 int(do_fade), _stream()), "sa_augment_views")
+
+
+def normalize_batch(x, y, shift, workspace, eps):
+    check(lib().sa_normalize_batch(_p(_req(x, F32, "x")), _p(y), x.numel(), float(shift), _p(workspace), float(eps), _stream()),
+          "sa_normalize_batch")
+
+
+def patchify_bf16(img, out, ph, pw):
+    S, _, F_, T_ = img.shape
+    check(lib().sa_patchify_bf16(_p(_req(img, F32, "img")), _p(_req(out, BF16, "out")), S, F_, T_, ph, pw, _stream()), "sa_patchify_bf16")
+
+
+# ------------------------------------------------------------------------------------------------ token bookkeeping
+def fill_cls(x, S, seq_stride, d, cls, pos0):
+    check(lib().sa_fill_cls(_p(x), S, seq_stride, d, _p(cls), _p(pos0), _stream()), "sa_fill_cls")
+
+
+def cls_grad(dx, S, seq_stride, d, dcls):
+    check(lib().sa_cls_grad(_p(dx), S, seq_stride, d, _p(dcls), _stream()), "sa_cls_grad")
+
+
+def gather_rows(src, src_seq_stride, src_row0, idx, dst, dst_seq_stride, dst_row0, S, d):
+    check(lib().sa_gather_rows(_p(src), src_seq_stride, src_row0, _p(idx), idx.shape[1], _p(dst), dst_seq_stride, dst_row0, S, d, _stream()),
+          "sa_gather_rows")
+
+
+def scatter_add_rows(src, src_seq_stride, src_row0, idx, dst, dst_seq_stride, dst_row0, S, d):
+    check(lib().sa_scatter_add_rows(_p(src), src_seq_stride, src_row0, _p(idx), idx.shape[1], _p(dst), dst_seq_stride, dst_row0, S, d,
+                                    _stream()), "sa_scatter_add_rows")
+
+
+def device_info():
+    name = C.create_string_buffer(128)
+    cus = C.c_int32(0)
+    check(lib().sa_device_info(name, 128, C.byref(cus)), "sa_device_info")
+    return name.value.decode(), cus.value

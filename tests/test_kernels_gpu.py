@@ -1,0 +1,367 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a CPU restatement of the same op
+(fp64/fp32 PyTorch or the oracle), on seeded inputs.  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ssl_audio_amd import ops  # noqa: E402
+from ssl_audio_amd import frontend as fe  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    ops.lib()  # fails loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("a_km,b_km", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (384, 192, 256), (200, 72, 64), (128, 128, 64 * 7)])
+def test_gemm_layouts(dev, a_km, b_km, M, N, K):
+    """All four operand layouts, ragged M/N tiles; bf16 inputs are exact, fp32 accumulation: rel err <= 1e-5."""
+    A = bf(rnd((M, K), 1)); B = bf(rnd((N, K), 2))
+    ref = A.double() @ B.double().T
+    Ad = (A if a_km else A.T.contiguous()).to(dev)
+    Bd = (B if b_km else B.T.contiguous()).to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_f32=out)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 1e-5
+    # asymmetric check (a transposed C write would pass a symmetric problem): single hot element
+    A2 = torch.zeros(M, K); A2[3, 5] = 1.0
+    B2 = torch.zeros(N, K); B2[7, 5] = 2.0
+    ops.gemm((bf(A2) if a_km else bf(A2).T.contiguous()).to(dev), (bf(B2) if b_km else bf(B2).T.contiguous()).to(dev),
+             a_kmajor=a_km, b_kmajor=b_km, out_f32=out)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert o[3, 7] == 2.0 and o.abs().sum() == 2.0
+
+
+def test_gemm_epilogues(dev):
+    M, N, K = 300, 192, 128
+    A = bf(rnd((M, K), 3)); W = bf(rnd((N, K), 4, 0.1)); bias = rnd((N,), 5); res = rnd((M, N), 6)
+    acc = A.double() @ W.double().T
+    # bias + GELU, pre-activation side output, bf16 + fp32 outputs
+    out32 = torch.empty(M, N, device=dev); out16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=1, aux_out=pre, out_f32=out32, out_bf16=out16)
+    h = acc + bias.double()
+    ref = torch.nn.functional.gelu(h)
+    assert rel_err(out32, ref) < 2e-5
+    assert rel_err(out16, ref) < 4e-3          # bf16 rounding of the output
+    assert rel_err(pre, h) < 4e-3
+    # GELU' epilogue (backward through fc1 activation): dH = dA * gelu'(h)
+    hb = bf(h.float())
+    ops.gemm(A.to(dev), W.to(dev), act=2, aux_in=hb.to(dev), out_f32=out32)
+    hh = hb.double().requires_grad_(True)
+    torch.nn.functional.gelu(hh).sum().backward()
+    assert rel_err(out32, acc * hh.grad) < 2e-5
+    # bias + residual, alpha, accumulate
+    ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), residual=res.to(dev), alpha=0.5, out_f32=out32)
+    assert rel_err(out32, 0.5 * acc + bias.double() + res.double()) < 1e-5
+    ops.gemm(A.to(dev), W.to(dev), out_f32=out32, accumulate=True)
+    assert rel_err(out32, 1.5 * acc + bias.double() + res.double()) < 1e-5
+    # patch-embed style: residual indexed modulo a period and output rows scattered past a CLS row
+    per = 20
+    pos = rnd((per, N), 7)
+    tok = torch.zeros(M // per * (per + 1), N, device=dev)
+    ops.gemm(A[:M // per * per].contiguous().to(dev), W.to(dev), bias=bias.to(dev), residual=pos.to(dev), res_mod=per, row_group=per, out_f32=tok)
+    t = tok.cpu().view(M // per, per + 1, N)
+    refp = (acc[:M // per * per] + bias.double()).view(M // per, per, N) + pos.double()
+    assert rel_err(t[:, 1:], refp) < 1e-5 and float(t[:, 0].abs().max()) == 0.0
+
+
+def test_gemm_split_k_wgrad(dev):
+    """TN (wgrad) with a long ragged reduction and split-K atomics into a zeroed fp32 buffer."""
+    Mtok, N, K = 1000, 192, 256
+    dY = bf(rnd((Mtok, N), 8)); X = bf(rnd((Mtok, K), 9))
+    ref = dY.double().T @ X.double()
+    out = torch.zeros(N, K, device=dev)
+    split = 4
+    ops.gemm(dY.to(dev), X.to(dev), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split)
+    assert rel_err(out, ref) < 1e-5
+    assert ops.pick_split_k(768, 768, 63744) >= 8
+
+
+def test_cast_and_colsum(dev):
+    x = rnd((1000, 300), 10)
+    y = ops.cast_bf16(x.to(dev))
+    assert torch.equal(y.cpu(), bf(x))
+    out = torch.empty(300, device=dev)
+    ops.colsum_bf16(y, out)
+    assert rel_err(out, bf(x).double().sum(0)) < 1e-5
+    ops.colsum_bf16(y, out, accumulate=True)
+    assert rel_err(out, 2 * bf(x).double().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(257, 768), (64, 192), (33, 1024), (5, 64)])
+def test_layernorm(dev, M, D):
+    x = rnd((M, D), 11, 2.0) + 0.3; g = rnd((D,), 12) * 0.2 + 1; b = rnd((D,), 13) * 0.2
+    xd = x.double().requires_grad_(True); gd = g.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-6)
+    y32 = torch.empty(M, D, device=dev); y16 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), 1e-6, y_bf16=y16, y_f32=y32, mean=mean, rstd=rstd)
+    assert rel_err(y32, ref) < 2e-6 and rel_err(y16, ref) < 4e-3
+    dy = rnd((M, D), 14); dres = rnd((M, D), 15)
+    ref.backward(dy.double())
+    dx = torch.empty(M, D, device=dev); dx16 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres=dres.to(dev), dx_f32=dx, dx_bf16=dx16, dgamma=dg, dbeta=db)
+    assert rel_err(dx, xd.grad + dres.double()) < 5e-6
+    assert rel_err(dx16, xd.grad + dres.double()) < 4e-3
+    assert rel_err(dg, gd.grad) < 1e-5 and rel_err(db, bd.grad) < 1e-5
+    # bf16 upstream gradient path (what the dgrad GEMMs hand over)
+    ops.layernorm_bwd(bf(dy).to(dev), x.to(dev), g.to(dev), mean, rstd, dx_f32=dx)
+    xd.grad = None
+    torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-6).backward(bf(dy).double())
+    assert rel_err(dx, xd.grad) < 5e-6
+
+
+def test_layernorm_strided_cls_rows(dev):
+    """Final norm on the CLS rows only: x viewed with ld = N*d."""
+    S, N, D = 6, 25, 192
+    x = rnd((S, N, D), 16); g = torch.ones(D); b = torch.zeros(D)
+    y = torch.empty(S, D, device=dev)
+    xd = x.to(dev)
+    ops.layernorm_fwd(xd.view(S, N * D)[:, :D], g.to(dev), b.to(dev), 1e-6, y_f32=y)
+    assert rel_err(y, torch.nn.functional.layer_norm(x[:, 0].double(), (D,))) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, H, N):
+    rows, w = qkv.shape
+    C_ = w // 3
+    S = rows // N
+    q, k, v = qkv.double().view(S, N, 3, H, C_ // H).permute(2, 0, 3, 1, 4)
+    a = ((q @ k.transpose(-2, -1)) * (C_ // H) ** -0.5).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(rows, C_)
+
+
+@pytest.mark.parametrize("S,H,N", [(3, 3, 249), (2, 2, 25), (2, 1, 63), (1, 12, 256), (2, 2, 40), (1, 1, 1)])
+def test_attention_fwd_bwd(dev, S, H, N):
+    """bf16 in/out, P in bf16: forward rel err <= 1e-2 vs fp64 on the same bf16 inputs, gradients <= 2e-2."""
+    C_ = 64 * H
+    qkv = bf(rnd((S * N, 3 * C_), 17, 1.0))
+    # an outlier key per sequence exercises the max-subtraction
+    qkv[5 % (S * N), C_:C_ + 64] *= 6.0
+    qd = qkv.double().requires_grad_(True)
+    ref = attn_ref(qd, H, N)
+    out = torch.full((S * N, C_), float("nan"), device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(S * H, N, device=dev)
+    ops.attention_fwd(qkv.to(dev), H, N, 0.125, out, lse)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) < 1e-2
+    q, k, _ = qkv.double().view(S, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * 0.125, -1).reshape(S * H, N)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-2
+    dout = bf(rnd((S * N, C_), 18))
+    ref.backward(dout.double())
+    dqkv = torch.full((S * N, 3 * C_), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.attention_bwd(qkv.to(dev), H, N, 0.125, out, dout.to(dev), lse, dqkv)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in [("dq", slice(0, C_)), ("dk", slice(C_, 2 * C_)), ("dv", slice(2 * C_, 3 * C_))]:
+        assert rel_err(dqkv[:, sl], qd.grad[:, sl]) < 2e-2, name
+
+
+# ------------------------------------------------------------------------------------------------ BN pieces / loss pieces
+@pytest.mark.parametrize("B,C_", [(128, 8192), (7, 24), (32, 256)])
+def test_bn_pieces(dev, B, C_):
+    x = rnd((B, C_), 19, 1.5) + 0.2; g = rnd((C_,), 20) * 0.2 + 1; b = rnd((C_,), 21) * 0.2
+    xd = x.double().requires_grad_(True); gd = g.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    mu = xd.mean(0); var = xd.var(0, unbiased=False)
+    ref = torch.relu((xd - mu) * torch.rsqrt(var + 1e-5) * gd + bd)
+    mean = torch.empty(C_, device=dev); m2 = torch.empty(C_, device=dev)
+    ops.bn_colstats(x.to(dev), mean, m2)
+    assert rel_err(mean, mu) < 1e-5 and rel_err(m2 / B, var) < 1e-5
+    rstd = torch.rsqrt(m2 / B + 1e-5)
+    y = torch.empty(B, C_, device=dev); y16 = torch.empty(B, C_, device=dev, dtype=torch.bfloat16)
+    ops.bn_apply(x.to(dev), mean, rstd, g.to(dev), b.to(dev), True, y_f32=y, y_bf16=y16)
+    assert rel_err(y, ref) < 5e-6 and rel_err(y16, ref) < 4e-3
+    dy = rnd((B, C_), 22)
+    ref.backward(dy.double())
+    s1 = torch.empty(C_, device=dev); s2 = torch.empty(C_, device=dev)
+    ops.bn_bwd_stats(dy.to(dev), x.to(dev), mean, rstd, g.to(dev), b.to(dev), True, s1, s2)
+    assert rel_err(s1, bd.grad) < 1e-5 and rel_err(s2, gd.grad) < 1e-5
+    dx = torch.empty(B, C_, device=dev)
+    ops.bn_bwd_apply(dy.to(dev), x.to(dev), mean, rstd, g.to(dev), b.to(dev), True, s1, s2, 1.0 / B, dx_f32=dx)
+    assert rel_err(dx, xd.grad) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (24, 24, 7), (128, 256, 256), (33, 70, 65)])
+def test_matmul_f32(dev, M, N, K):
+    """Exact-fp32 MFMA: error of an fp32 dot product (<= 1e-6 relative), all transposes."""
+    A = rnd((M, K), 23); B = rnd((K, N), 24)
+    ref = A.double() @ B.double()
+    out = torch.empty(M, N, device=dev)
+    ops.matmul_f32(A.to(dev), B.to(dev), out)
+    assert rel_err(out, ref) < 1e-6
+    ops.matmul_f32(A.T.contiguous().to(dev), B.to(dev), out, trans_a=True, alpha=0.5)
+    assert rel_err(out, 0.5 * ref) < 1e-6
+    ops.matmul_f32(A.to(dev), B.T.contiguous().to(dev), out, trans_b=True)
+    assert rel_err(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("hsic", [False, True])
+def test_bt_loss_grad(dev, hsic):
+    D = 256
+    c = rnd((D, D), 25, 0.1) + torch.eye(D) * 0.9
+    cd = c.double().requires_grad_(True)
+    on = (torch.diagonal(cd) - 1).pow(2).sum()
+    offm = cd - torch.diag(torch.diagonal(cd))
+    off = ((offm + (1 - torch.eye(D, dtype=torch.float64))) if hsic else offm).pow(2).sum()
+    ref = 1.0 * on + 0.005 * off
+    ref.backward()
+    loss = torch.empty(1, device=dev); G = torch.empty(D, D, device=dev)
+    ops.bt_loss_grad(c.to(dev), 1.0, 0.005, hsic, loss, G)
+    assert abs(float(loss) - float(ref)) / float(ref) < 1e-5
+    assert rel_err(G, cd.grad) < 1e-6
+
+
+def test_adamw_and_ema(dev):
+    n = 100003
+    p = rnd((n,), 26); g = rnd((n,), 27, 0.1)
+    pr = torch.nn.Parameter(p.clone().double())
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.06)
+    pd, m, v = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p16 = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for step in (1, 2, 3):
+        pr.grad = g.double() * step
+        opt.step()
+        ops.adamw_step(pd, (g * step).to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.06, step, p_bf16=p16)
+    assert float((pd.cpu().double() - pr.data).abs().max()) < 2e-6
+    assert torch.equal(p16.cpu(), bf(pd.cpu()))
+    t = rnd((n,), 28).to(dev)
+    t0 = t.cpu().clone()
+    ops.ema_update(t, pd, 0.99)
+    assert float((t.cpu() - (0.99 * t0 + 0.01 * pd.cpu())).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ frontend
+def synth_wave(n, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(L, dtype=torch.float64) / 16000.0
+    w = 0.1 * torch.randn(n, L, generator=g, dtype=torch.float64)
+    for _ in range(3):
+        f = 100 + 6900 * torch.rand(n, 1, generator=g, dtype=torch.float64)
+        a = 0.05 + 0.45 * torch.rand(n, 1, generator=g, dtype=torch.float64)
+        w = w + a * torch.sin(2 * math.pi * f * t)
+    return w.float()
+
+
+@pytest.mark.parametrize("L,T,start", [(160000, 1001, 0), (16000, 101, 0), (15200, 96, 0), (16000, 96, 3), (16000, 120, 0)])
+def test_logmel(dev, L, T, start):
+    """fp32 FFT vs the fp64 oracle: |diff| <= 2e-3 in the log-mel domain (values span ~[-8, 6])."""
+    from oracle import frontend as ofe
+    wave = synth_wave(3, L, 29)
+    mel = fe.MelSpectrogram()
+    out = mel(wave.to(dev), crop_frames=T, start=start, norm_stats=(-0.8294, 4.6230))
+    ref = ofe.crop_pad_normalize(ofe.logmel(wave.numpy()), T, start, -0.8294, 4.6230)
+    d = np.abs(out.cpu().numpy()[:, 0] - ref)
+    assert out.shape == (3, 1, 64, T)
+    assert d.max() < 2e-3, d.max()
+
+
+# ------------------------------------------------------------------------------------------------ augmentation
+def run_views(dev, lms, recs, out_size, canvas, vcs_ratio, do_fade=True):
+    V = len(recs)
+    F_in, T_in = lms.shape[-2:]
+    params = torch.zeros(V, 8)
+    src = torch.zeros(V, dtype=torch.int32); mix = torch.full((V,), -1, dtype=torch.int32)
+    for v, r in enumerate(recs):
+        i, j, h, w = r["rrc"]
+        ht = r.get("head_tail", (0.0, 0.0))
+        params[v] = torch.tensor([r.get("alpha", 0.0), i, j, h, w, ht[0], ht[1], 0.0])
+        src[v] = r["src"]; mix[v] = r.get("mix", -1)
+    out = torch.empty(V, 1, out_size[0], out_size[1], device=dev)
+    ops.augment_views(lms.to(dev), F_in * T_in, src.to(dev), mix.to(dev), params.to(dev), out, F_in, T_in, canvas, vcs_ratio, do_fade)
+    return out.cpu().numpy()
+
+
+def test_augment_rrc_golden(dev, golden):
+    """RandomResizeCrop alone against vectors captured from the reference: |diff| <= 1e-4."""
+    g = golden("augment")
+    for tag in ["t96", "t96b", "t1001", "t1001b", "local"]:
+        x = torch.from_numpy(g[f"rrc_{tag}_x"])
+        cfg = g[f"rrc_{tag}_cfg"]
+        out_size = (int(cfg[0]), int(cfg[1]))
+        canvas = (int(x.shape[-2] * cfg[2]), int(x.shape[-1] * cfg[3]))
+        rec = {"rrc": tuple(int(v) for v in g[f"rrc_{tag}_params"]), "src": 0}
+        y = run_views(dev, x, [rec], out_size, canvas, canvas[1] / max(out_size[1] - 1, 1), do_fade=False)
+        assert np.abs(y[0] - g[f"rrc_{tag}_y"]).max() < 1e-4, tag
+
+
+@pytest.mark.parametrize("tag", ["seq96", "seq208"])
+def test_augment_sequence_golden(dev, golden, tag):
+    """Whole AudioPairTransform sequence (mixup bank + RRC + fader) against the reference's outputs, driven by the
+    oracle's recorded draws: the batched kernel reproduces the sequential bank semantics exactly."""
+    from oracle import augment as oaug
+    g = golden("augment")
+    clips = g[f"apt_{tag}_clips"]
+    T_ = clips.shape[-1]
+    tfm = oaug.PairTransformOracle(crop_frames=T_, seed=int(g[f"apt_{tag}_seed"]))
+    for c in clips:
+        tfm(c)
+    recs = []
+    for e, r in enumerate(tfm.records):          # event e = 2*clip + view; bank entry k <-> clip k // 2
+        recs.append({"alpha": r["alpha"], "rrc": r["rrc"], "head_tail": r["head_tail"], "src": e // 2,
+                     "mix": r["bank_index"] // 2 if r["bank_index"] >= 0 else -1})
+    lms = torch.from_numpy(clips[:, 0])
+    canvas = (64, int(T_ * 1.5))
+    y = run_views(dev, lms, recs, (64, T_), canvas, canvas[1] / (T_ - 1))
+    ref = g[f"apt_{tag}_views"].reshape(-1, 1, 64, T_)
+    assert np.abs(y - ref).max() < 2e-4
+
+
+def test_normalize_batch_and_patchify(dev):
+    x = rnd((5, 1, 64, 96), 30, 3.0) + 1
+    y = torch.empty_like(x, device=dev); ws = torch.zeros(2, dtype=torch.float64, device=dev)
+    ops.normalize_batch(x.to(dev), y, 1.0, ws, 1.1920929e-07)
+    ref = (x.double() - x.double().mean()) / x.double().std()
+    assert float((y.cpu().double() - ref).abs().max()) < 5e-6
+    img = rnd((3, 1, 64, 1001), 31)
+    out = torch.empty(3 * 4 * 62, 256, device=dev, dtype=torch.bfloat16)
+    ops.patchify_bf16(img.to(dev), out, 16, 16)
+    ref = img[..., :992].reshape(3, 1, 4, 16, 62, 16).permute(0, 2, 4, 3, 5, 1).reshape(3 * 248, 256)
+    assert torch.equal(out.cpu(), bf(ref))
+
+
+def test_token_ops(dev):
+    S, N, d = 4, 9, 64
+    x = torch.zeros(S, N, d, device=dev); cls = rnd((d,), 32).to(dev); pos0 = rnd((d,), 33).to(dev)
+    ops.fill_cls(x, S, N * d, d, cls, pos0)
+    assert torch.allclose(x[:, 0].cpu(), (cls + pos0).cpu().expand(S, d)) and float(x[:, 1:].abs().max()) == 0
+    dx = rnd((S, N, d), 34).to(dev); dcls = torch.zeros(d, device=dev)
+    ops.cls_grad(dx, S, N * d, d, dcls)
+    assert rel_err(dcls, dx[:, 0].sum(0)) < 1e-6
+    idx = torch.stack([torch.randperm(N - 1)[:5] for _ in range(S)]).to(torch.int32).to(dev)
+    src = rnd((S, N, d), 35).to(dev); dst = torch.zeros(S, 6, d, device=dev)
+    ops.gather_rows(src, N * d, 1, idx, dst, 6 * d, 1, S, d)
+    ref = torch.gather(src[:, 1:], 1, idx.long().unsqueeze(-1).expand(-1, -1, d))
+    assert torch.equal(dst[:, 1:], ref)
+    back = torch.zeros(S, N, d, device=dev)
+    ops.scatter_add_rows(dst, 6 * d, 1, idx, back, N * d, 1, S, d)
+    chk = torch.zeros(S, N - 1, d, device=dev).scatter_add_(1, idx.long().unsqueeze(-1).expand(-1, -1, d), ref)
+    assert torch.equal(back[:, 1:], chk)
