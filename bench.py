@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of the Barlow Twins pre-training step (10 s @ 16 kHz -> 64-mel, ViT-B, BT loss).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the whole hot path over one batch of synthetic waveforms already resident in HBM:
+log-mel frontend -> 2 augmented views -> encoder+projector fwd -> BT loss -> bwd -> grad all-reduce -> AdamW.
+Per-GPU batch is fixed (weak scaling): 128 clips/GPU, i.e. BASELINE config 3 (global batch 1024) at N = 8.
+Rank 0 prints ONE JSON line (metric, value, roofline of the dominant kernel, CPU baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (model_type, seconds, clips per GPU, mode)
+    "vit_base_bt_10s": ("vit_base", 10.0, 128, "bt"),        # BASELINE configs[2] per-GPU shard (metric's config)
+    "vit_tiny_bt_10s": ("vit_tiny", 10.0, 256, "bt"),        # BASELINE configs[1]
+    "vit_base_byol_10s": ("vit_base", 10.0, 128, "byol"),    # BASELINE configs[3]
+}
+GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol_10s": 357.6}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(workload, budget_clips=4, steps=2):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+    from oracle import step as ostep, vit as ovit
+    from ssl_audio_amd.selfcheck import synthetic_waveforms
+    from oracle import frontend as ofe, augment as oaug
+    import numpy as np
+    model_type, seconds, _, _ = WORKLOADS[workload]
+    size = model_type.split("_")[-1]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_samples = int(seconds * 16000)
+    T = n_samples // 160 + 1
+    heads = {"tiny": 3, "small": 6, "base": 12}[size]
+    d = ovit.VIT_SIZES[size]["embed_dim"]
+    enc = ovit.init_params(size, seed=0)
+    sd = {"backbone.encoder.encoder." + k: v for k, v in enc.items()}
+    g = torch.Generator().manual_seed(1)
+    sd["head.projector.0.weight"] = torch.randn(8192, d, generator=g) * 0.02
+    sd["head.projector.1.weight"], sd["head.projector.1.bias"] = torch.ones(8192), torch.zeros(8192)
+    sd["head.projector.1.running_mean"], sd["head.projector.1.running_var"] = torch.zeros(8192), torch.ones(8192)
+    sd["head.projector.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    sd["head.projector.3.weight"] = torch.randn(256, 8192, generator=g) * 0.02
+    opt = ostep.AdamW(1e-4, 0.06)
+    waves = synthetic_waveforms(budget_clips, n_samples).numpy()
+    tfm = oaug.PairTransformOracle(crop_frames=T, seed=0)
+
+    def one_step():
+        lms = ofe.crop_pad_normalize(ofe.logmel(waves, dtype=np.float32), T, 0, -0.8294, 4.6230)
+        v = [[], []]
+        for b in range(budget_clips):
+            c = tfm(lms[b][None])
+            v[0].append(c[0]); v[1].append(c[1])
+        views = [torch.from_numpy(np.stack(x)).float() for x in v]
+        return ostep.bt_step(sd, views, heads, (4, 6), opt)[0]
+
+    one_step()                                    # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        one_step()
+    dt = time.time() - t0
+    return {"value": budget_clips * steps / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{budget_clips} clips x {steps} steps after 1 warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
+                      f"{torch.get_num_threads()} threads (oracle/: frontend + augment + fwd/bwd + AdamW)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="vit_base_bt_10s", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch_per_gpu", type=int, default=None)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ssl_audio_amd import dist as sdist, hyperparameters as hp, ops
+    from ssl_audio_amd.selfcheck import synthetic_waveforms
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+
+    rank, local, world = sdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ops.lib()                                                      # fail loudly if the HIP library is missing
+
+    model_type, seconds, bpg, mode = WORKLOADS[args.workload]
+    B = args.batch_per_gpu or bpg
+    n_samples = int(seconds * 16000)
+    cfg = hp.make_args(model_type=model_type, batch_size=B * world, crop_frames=n_samples // 160 + 1, dataset="audioset",
+                       stop_gradient=(mode == "byol"), predictor=(mode == "byol"))
+    trainer = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=B, clip_samples=n_samples, seed=0)
+
+    # synthetic waveforms resident in HBM: 2 alternating batches, distinct per rank (cheap device-side recipe of the
+    # same family as BASELINE.md §3: noise + 3 sinusoids)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    t = torch.arange(n_samples, device=dev, dtype=torch.float32) / 16000.0
+    pool = []
+    for _ in range(2):
+        w = 0.1 * torch.randn(B, n_samples, device=dev, generator=g)
+        for _ in range(3):
+            f = 100.0 + 6900.0 * torch.rand(B, 1, device=dev, generator=g)
+            a = 0.05 + 0.45 * torch.rand(B, 1, device=dev, generator=g)
+            w += a * torch.sin(2 * torch.pi * f * t)
+        pool.append(w.contiguous())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(pool[i % 2])
+    barrier()
+    ops.GEMM_PROFILE = []                                          # HIP events around every GEMM launch of the timed region
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.step(pool[i % 2])
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss)
+
+    if rank == 0:
+        clips_per_s = B * world * args.steps / dt
+        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
+        gemm_flop = sum(fl for _, _, fl, _ in prof)
+        n_launch = max(len(prof), 1)
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        by_kind = {}
+        for e0, e1, fl, kind in prof:
+            ms, f = by_kind.get(kind, (0.0, 0.0))
+            by_kind[kind] = (ms + e0.elapsed_time(e1), f + fl)
+        line = {
+            "metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref",
+            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": args.workload, "encoder": model_type, "clip_seconds": seconds, "n_mels": 64,
+                       "clips_per_gpu": B, "global_batch": B * world, "step": "logmel+augment+fwd+bwd+allreduce+adamw" +
+                       ("+ema" if mode == "byol" else ""), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
+                       "loss": round(loss_val, 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 16x16x32, all layouts: fwd NT / dgrad NN / wgrad TN)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": len(prof), "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                         "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
+                         "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0},
+                         "whole_step_tflops": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,10 @@ int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32
  *   bwd_stats: s1[c] = sum_b g, s2[c] = sum_b g*xhat, g = dy * [ReLU mask]  (dbeta = s1, dgamma = s2)
  *   bwd_apply: dx = gamma * rstd * (g - s1*inv_n - xhat * s2*inv_n), s1/s2 summed over ranks, inv_n = 1/global rows */
 int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, float* mean, float* m2, void* stream);
+/* finalize: combine W ranks' (mean, m2) rows ([W][2][C], equal rows_per_rank) -> global mean, rstd = rsqrt(var+eps);
+ * optionally updates running_mean / running_var (momentum, unbiased variance) as nn.BatchNorm1d does in train mode */
+int sa_bn_finalize(const float* stats, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum, float* mean,
+                   float* rstd, float* running_mean, float* running_var, void* stream);
 int sa_bn_apply(const float* x, int64_t ld, int32_t B, int32_t C, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, int32_t relu, float* y_f32, void* y_bf16, int64_t ldy, void* stream);
 int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
@@ -98,7 +102,8 @@ int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy, const floa
                     float* s2, void* stream);
 int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
                     const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* s1,
-                    const float* s2, float inv_n, float* dx_f32, void* dx_bf16, int64_t lddx, void* stream);
+                    const float* s2, float inv_n, const float* out_scale /* device scalar or NULL */, float* dx_f32, void* dx_bf16,
+                    int64_t lddx, void* stream);
 
 /* ------------------------------------------------------------------ Barlow Twins loss pieces (fp32, exact-fp32 MFMA)
  * Replaces utils/loss.py:15-30.  sa_matmul_f32: C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
@@ -114,6 +119,8 @@ int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_
 int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream);
 int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream);
+/* y += a * x on flat fp32 buffers (gradient accumulation of small vectors) */
+int sa_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);
 
 /* ------------------------------------------------------------------ log-mel frontend
  * Replaces torchaudio MelSpectrogram + log at datasets.py:39-48,115 and crop/pad/normalise at datasets.py:342-354.

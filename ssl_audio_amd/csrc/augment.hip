@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   // source-column window of this slab (crop coordinates), align_corners=True
   const float sx = T_out > 1 ? (float)(cw - 1) / (float)(T_out - 1) : 0.f;
   const float sy = F_out > 1 ? (float)(ch - 1) / (float)(F_out - 1) : 0.f;
-  const int xlo = max(0, (int)floorf(sx * (float)t0) - 1);
-  const int xhi = min(cw - 1, (int)floorf(sx * (float)(t0 + nt - 1)) + 2);
+  const int xlo = max(0, (int)floorf(__fmul_rn(sx, (float)t0)) - 1);
+  const int xhi = min(cw - 1, (int)floorf(__fmul_rn(sx, (float)(t0 + nt - 1))) + 2);
   const int wt = xhi - xlo + 1;  // host guarantees wt <= LDS_W via TT
 
   // ---- stage 1: mixed source tile [ch x wt]
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   for (int idx = threadIdx.x; idx < F_out * nt; idx += 256) {
     const int fy = idx / nt, tx = idx - fy * nt;
     const int t = t0 + tx;
-    const float rx = sx * (float)t, ry = sy * (float)fy;
+    // rounded products (no FMA contraction into the fraction): PyTorch's CPU kernel rounds scale*index to fp32 first
+    const float rx = __fmul_rn(sx, (float)t), ry = __fmul_rn(sy, (float)fy);
     const float fx = floorf(rx), fyf = floorf(ry);
     float wx[4], wy[4];
     cubic_w(rx - fx, wx);

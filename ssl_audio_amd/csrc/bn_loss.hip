@@ -29,6 +29,28 @@ __global__ void bn_colstats_kernel(const float* __restrict__ x, int64_t ld, int 
   m2_out[c] = q;
 }
 
+// ---- combine per-rank (mean, M2) (Chan et al., equal row counts), produce mean / rstd and update the running buffers
+// stats: [W][2][C] (rank-major; [r][0] = mean_r, [r][1] = M2_r).  running_var uses the unbiased variance (PyTorch).
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int W, int rows_per_rank, int C, float eps, float momentum,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean = 0.f;
+  for (int r = 0; r < W; ++r) mean += stats[((int64_t)r * 2) * C + c];
+  mean /= (float)W;
+  float m2 = 0.f;
+  for (int r = 0; r < W; ++r) {
+    const float d = stats[((int64_t)r * 2) * C + c] - mean;
+    m2 += stats[((int64_t)r * 2 + 1) * C + c] + (float)rows_per_rank * d * d;
+  }
+  const float n = (float)W * (float)rows_per_rank;
+  mean_out[c] = mean;
+  rstd_out[c] = rsqrtf(m2 / n + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.f, 1.f));
+}
+
 // ---- y = (x - mean) * rstd [* gamma + beta] [relu]; rstd = rsqrt(var + eps) is given
 __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t ld, int B, int C, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -71,8 +93,10 @@ template <typename DY>
 __global__ void bn_bwd_apply_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ld, int B, int C,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, int relu, const float* __restrict__ s1, const float* __restrict__ s2,
-                                    float inv_n, float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx) {
+                                    float inv_n, const float* __restrict__ out_scale, float* __restrict__ dx_f32,
+                                    bf16_t* __restrict__ dx_bf16, int64_t lddx) {
   const int64_t n = (int64_t)B * C;
+  const float osc = out_scale ? *out_scale : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / C), c = (int)(i % C);
     const float r = rstd[c];
@@ -80,7 +104,7 @@ __global__ void bn_bwd_apply_kernel(const DY* __restrict__ dy, int64_t lddy, con
     const float xh = (x[(int64_t)b * ld + c] - mean[c]) * r;
     float d = (float)dy[(int64_t)b * lddy + c];
     if (relu && !(xh * g + bt > 0.f)) d = 0.f;
-    const float o = g * r * (d - s1[c] * inv_n - xh * s2[c] * inv_n);
+    const float o = osc * g * r * (d - s1[c] * inv_n - xh * s2[c] * inv_n);
     if (dx_f32) dx_f32[(int64_t)b * lddx + c] = o;
     if (dx_bf16) dx_bf16[(int64_t)b * lddx + c] = f2bf(o);
   }
@@ -172,6 +196,10 @@ __global__ void ema_kernel(float* __restrict__ tgt, const float* __restrict__ sr
     tgt[i] = tgt[i] * beta + (1.f - beta) * src[i];
 }
 
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+
 inline int flat_grid(int64_t n, int per_thread = 1) {
   const int64_t want = (n + 256LL * per_thread - 1) / (256LL * per_thread);
   return (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
@@ -183,6 +211,15 @@ extern "C" int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, 
   SA_CHECK_ARG(x && mean && m2 && B > 0 && C > 0, "sa_bn_colstats: bad args");
   hipLaunchKernelGGL(bn_colstats_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, ld, B, C, mean, m2);
   SA_LAUNCH_CHECK("sa_bn_colstats");
+  return 0;
+}
+
+extern "C" int sa_bn_finalize(const float* stats, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum, float* mean,
+                              float* rstd, float* running_mean, float* running_var, void* stream) {
+  SA_CHECK_ARG(stats && mean && rstd && W > 0 && rows_per_rank > 0 && C > 0, "sa_bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, W, rows_per_rank, C, eps, momentum,
+                     mean, rstd, running_mean, running_var);
+  SA_LAUNCH_CHECK("sa_bn_finalize");
   return 0;
 }
 
@@ -212,15 +249,16 @@ extern "C" int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy,
 
 extern "C" int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
                                const float* mean, const float* rstd, const float* gamma, const float* beta, int32_t relu, const float* s1,
-                               const float* s2, float inv_n, float* dx_f32, void* dx_bf16, int64_t lddx, void* stream) {
+                               const float* s2, float inv_n, const float* out_scale, float* dx_f32, void* dx_bf16, int64_t lddx,
+                               void* stream) {
   SA_CHECK_ARG(dy && x && mean && rstd && s1 && s2 && (dx_f32 || dx_bf16) && B > 0 && C > 0, "sa_bn_bwd_apply: bad args");
   const int grid = flat_grid((int64_t)B * C);
   if (dy_is_bf16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, x, ld, B, C, mean,
-                       rstd, gamma, beta, relu, s1, s2, inv_n, dx_f32, (bf16_t*)dx_bf16, lddx);
+                       rstd, gamma, beta, relu, s1, s2, inv_n, out_scale, dx_f32, (bf16_t*)dx_bf16, lddx);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, x, ld, B, C, mean,
-                       rstd, gamma, beta, relu, s1, s2, inv_n, dx_f32, (bf16_t*)dx_bf16, lddx);
+                       rstd, gamma, beta, relu, s1, s2, inv_n, out_scale, dx_f32, (bf16_t*)dx_bf16, lddx);
   SA_LAUNCH_CHECK("sa_bn_bwd_apply");
   return 0;
 }
@@ -263,5 +301,13 @@ extern "C" int sa_ema_update(float* target, const float* online, int64_t n, floa
   if (n == 0) return 0;
   hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta);
   SA_LAUNCH_CHECK("sa_ema_update");
+  return 0;
+}
+
+extern "C" int sa_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream) {
+  SA_CHECK_ARG(y && x && n >= 0, "sa_axpy_f32: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, y, x, n, a);
+  SA_LAUNCH_CHECK("sa_axpy_f32");
   return 0;
 }

@@ -1,0 +1,61 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU
+for tests).  Only the exchanges SURVEY.md §8(e) lists exist:
+
+  * BN statistics of the projector / predictor / loss  (all-gather of 2*C floats per rank, combined on device)
+  * BN backward sums                                     (all-reduce of 2*C floats)
+  * the D x D cross-correlation matrix                   (all-reduce SUM, utils/loss.py:20-21)
+  * parameter gradients                                  (bucketed all-reduce SUM on a side stream, dp.py)
+
+Semantics are *global-batch exact*: W ranks with B/W clips each compute what one process computes on B clips
+(SURVEY.md F4); gradients are therefore SUMMED over ranks, not averaged.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def init_from_env(backend=None):
+    """torchrun-style initialisation (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
+    if "RANK" not in os.environ:
+        return 0, 0, 1
+    rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["WORLD_SIZE"])
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
+    return rank, local, world
+
+
+def all_gather_rows(t):
+    """[*shape] -> [W, *shape] (W = 1 without a process group: a view, no copy)."""
+    W = get_world_size()
+    if W == 1:
+        return t.unsqueeze(0)
+    out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def all_reduce_sum_(t):
+    if get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

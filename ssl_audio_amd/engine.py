@@ -1,0 +1,250 @@
+"""Explicit forward / backward schedule of the ViT encoder on the HIP kernels.
+
+This is the MI355X-side replacement for autograd tracing through models/mae.py:349-469: a fixed sequence of
+C-ABI launches per transformer block with fused epilogues and a hand-planned set of saved activations,
+
+  fwd block:  LN1 -> [qkv GEMM + (q,0,v) bias] -> fused attention -> [proj GEMM + bias + residual]
+              -> LN2 -> [fc1 GEMM + bias + GELU (pre-activation kept)] -> [fc2 GEMM + bias + residual]
+  bwd block:  mirrors it; every dgrad is an NN GEMM on the untransposed bf16 weight, every wgrad a TN split-K
+              GEMM accumulating fp32 atomics into the gradient buffer, GELU' fused into the fc2 dgrad epilogue,
+              LayerNorm backward fused with the residual-gradient add and emitting the bf16 copy the next
+              GEMMs consume.
+
+Residual stream fp32, GEMM operands / attention bf16, accumulation fp32.  `torch` only provides device
+memory here.  The autograd.Function at the bottom exposes the schedule to nn.Module callers.
+"""
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class _Bf16Cache:
+    """bf16 copies of fp32 parameters for the GEMMs, refreshed when the parameter's version changes."""
+
+    def __init__(self):
+        self._c = {}
+        self._manual = {}
+        self._pinned = {}
+
+    def mark_modified(self, p):
+        """Call after a HIP kernel rewrote `p` in place (those writes do not bump torch's version counter)."""
+        self._manual[id(p)] = self._manual.get(id(p), 0) + 1
+
+    def pin(self, p, w16):
+        """`w16` (a view of train.FlatState's bf16 buffer) is kept current by the optimiser kernel: always use it."""
+        self._pinned[id(p)] = (w16, p.data_ptr())
+
+    def get(self, p):
+        key = id(p)
+        pinned = self._pinned.get(key)
+        if pinned is not None and pinned[1] == p.data_ptr():
+            return pinned[0]
+        ent = self._c.get(key)
+        ver = (p._version, self._manual.get(key, 0))
+        if ent is None or ent[0] != ver or ent[1].device != p.device or ent[2] != p.data_ptr():
+            w = p.detach()
+            w2 = w.reshape(w.shape[0], -1) if w.dim() > 1 else w
+            ent = (ver, ops.cast_bf16(w2.contiguous()), p.data_ptr())
+            self._c[key] = ent
+        return ent[1]
+
+
+BF16_WEIGHTS = _Bf16Cache()
+
+# id(parameter) -> fp32 buffer (normally a view into train.FlatState's flat gradient buffer).  When a parameter has a
+# sink, the backward kernels accumulate straight into it and autograd is handed None (no per-parameter allocation,
+# no autograd accumulate pass, and the flat buffer is what the gradient all-reduce and the fused AdamW consume).
+GRAD_SINK = {}
+# called as BLOCK_DONE_HOOK(params_of_block) after each transformer block's backward (dp.GradSync overlaps the
+# gradient all-reduce of that block with the remaining backward)
+BLOCK_DONE_HOOK = None
+
+
+def grad_target(p):
+    """(buffer to accumulate d/dp into, value to return to autograd)."""
+    t = GRAD_SINK.get(id(p))
+    if t is not None:
+        return t, None
+    t = torch.zeros_like(p)
+    return t, t
+
+
+def _wgrad(dY16, X16, out):
+    """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip)."""
+    N, K = out.shape
+    split = ops.pick_split_k(N, K, dY16.shape[0])
+    if split > 1:
+        ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split)
+    else:
+        ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, accumulate=True)
+
+
+class BlockParams:
+    """Views of one transformer block's parameters (fp32 masters) -- key names follow models/mae.py."""
+    __slots__ = ("n1w", "n1b", "wqkv", "qb", "vb", "wp", "bp", "n2w", "n2b", "w1", "b1", "w2", "b2")
+
+    ORDER = __slots__
+
+    def __init__(self, tensors):
+        for n, t in zip(self.__slots__, tensors):
+            setattr(self, n, t)
+
+
+def block_forward(x, p, H, N, eps, save):
+    """x: fp32 [M, d] residual stream -> new fp32 [M, d].  `save` (list or None) receives the backward state."""
+    M, d = x.shape
+    dev = x.device
+    W = BF16_WEIGHTS.get
+    h1 = torch.empty(M, d, dtype=BF16, device=dev)
+    mean1, rstd1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, p.n1w, p.n1b, eps, y_bf16=h1, mean=mean1, rstd=rstd1)
+    qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
+    qkv_bias = torch.cat((p.qb.detach(), torch.zeros_like(p.vb), p.vb.detach()))  # k-bias is identically zero
+    ops.gemm(h1, W(p.wqkv), bias=qkv_bias, out_bf16=qkv)
+    ao = torch.empty(M, d, dtype=BF16, device=dev)
+    lse = torch.empty(M // N * H, N, device=dev)
+    ops.attention_fwd(qkv, H, N, (d // H) ** -0.5, ao, lse)
+    x2 = torch.empty(M, d, device=dev)
+    ops.gemm(ao, W(p.wp), bias=p.bp.detach(), residual=x, out_f32=x2)
+    h2 = torch.empty(M, d, dtype=BF16, device=dev)
+    mean2, rstd2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x2, p.n2w, p.n2b, eps, y_bf16=h2, mean=mean2, rstd=rstd2)
+    hidden = p.w1.shape[0]
+    pre = torch.empty(M, hidden, dtype=BF16, device=dev) if save is not None else None
+    a = torch.empty(M, hidden, dtype=BF16, device=dev)
+    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=1, aux_out=pre, out_bf16=a)
+    x3 = torch.empty(M, d, device=dev)
+    ops.gemm(a, W(p.w2), bias=p.b2.detach(), residual=x2, out_f32=x3)
+    if save is not None:
+        save.append((x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a))
+    return x3
+
+
+def block_backward(dx3, dx3_16, p, g, H, N, saved):
+    """dx3 fp32 / dx3_16 bf16: gradient of the block output.  g: BlockParams of fp32 gradient buffers (accumulated
+    into).  Returns (dx fp32, dx bf16) w.r.t. the block input."""
+    x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a = saved
+    M, d = x.shape
+    dev = x.device
+    W = BF16_WEIGHTS.get
+    # fc2
+    _wgrad(dx3_16, a, g.w2)
+    ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
+    dpre = torch.empty_like(pre)
+    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre)   # (dY W2) * GELU'(pre)
+    # fc1
+    _wgrad(dpre, h2, g.w1)
+    ops.colsum_bf16(dpre, g.b1, accumulate=True)
+    dh2 = torch.empty(M, d, dtype=BF16, device=dev)
+    ops.gemm(dpre, W(p.w1), b_kmajor=False, out_bf16=dh2)
+    del dpre
+    # LN2 + residual
+    dx2 = torch.empty(M, d, device=dev)
+    dx2_16 = torch.empty(M, d, dtype=BF16, device=dev)
+    ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_f32=dx2, dx_bf16=dx2_16, dgamma=g.n2w, dbeta=g.n2b)
+    # proj
+    _wgrad(dx2_16, ao, g.wp)
+    ops.colsum_bf16(dx2_16, g.bp, accumulate=True)
+    dao = dh2  # reuse
+    ops.gemm(dx2_16, W(p.wp), b_kmajor=False, out_bf16=dao)
+    # attention
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv)
+    # qkv
+    _wgrad(dqkv, h1, g.wqkv)
+    ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
+    ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
+    dh1 = dao
+    ops.gemm(dqkv, W(p.wqkv), b_kmajor=False, out_bf16=dh1)
+    del dqkv
+    # LN1 + residual
+    dx = torch.empty(M, d, device=dev)
+    dx_16 = dx2_16
+    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b)
+    return dx, dx_16
+
+
+class EncoderFn(torch.autograd.Function):
+    """tokens [S, N, d] fp32 (CLS + patch tokens, positional terms already added) -> transformer blocks -> final
+    LayerNorm.  Output: CLS latent [S, d] (pool='cls'), mean of patch tokens [S, d] (pool='mean') or the whole
+    normalised sequence [S, N, d] (pool='all').  Backward returns the gradient of the tokens and of every parameter.
+    """
+
+    @staticmethod
+    def forward(ctx, tokens, H, eps, pool, n_blocks, *params):
+        S, N, d = tokens.shape
+        blocks = [BlockParams(params[13 * i:13 * (i + 1)]) for i in range(n_blocks)]
+        nw, nb = params[13 * n_blocks], params[13 * n_blocks + 1]
+        need_grad = any(ctx.needs_input_grad)
+        save = [] if need_grad else None
+        x = tokens.detach().reshape(S * N, d)
+        for bp in blocks:
+            x = block_forward(x, bp, H, N, eps, save)
+        dev = x.device
+        if pool == "cls":
+            rows = x.view(S, N * d)[:, :d]
+            out = torch.empty(S, d, device=dev)
+            mean, rstd = torch.empty(S, device=dev), torch.empty(S, device=dev)
+            ops.layernorm_fwd(rows, nw, nb, eps, y_f32=out, mean=mean, rstd=rstd)
+        else:
+            y = torch.empty(S * N, d, device=dev)
+            mean, rstd = torch.empty(S * N, device=dev), torch.empty(S * N, device=dev)
+            ops.layernorm_fwd(x, nw, nb, eps, y_f32=y, mean=mean, rstd=rstd)
+            out = y.view(S, N, d)[:, 1:].mean(dim=1).contiguous() if pool == "mean" else y.view(S, N, d)
+        ctx.cfg = (S, N, d, H, pool, n_blocks)
+        ctx.saved = save
+        ctx.final = (x, mean, rstd)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        S, N, d, H, pool, n_blocks = ctx.cfg
+        params = ctx.params
+        x, mean, rstd = ctx.final
+        dev = x.device
+        grads, gz = [], []
+        for p in params:
+            if p.requires_grad:
+                buf, ret = grad_target(p)
+            else:
+                buf, ret = torch.zeros_like(p), None      # kernels always write somewhere
+            gz.append(buf)
+            grads.append(ret)
+        nw = params[13 * n_blocks]
+        gnw, gnb = gz[13 * n_blocks], gz[13 * n_blocks + 1]
+        dout = dout.contiguous().float()
+        M = S * N
+        if pool == "cls":
+            dx = torch.zeros(M, d, device=dev)
+            dx16 = torch.zeros(M, d, dtype=BF16, device=dev)
+            ops.layernorm_bwd(dout, x.view(S, N * d)[:, :d], nw, mean, rstd, dx_f32=dx.view(S, N * d)[:, :d],
+                              dx_bf16=dx16.view(S, N * d)[:, :d], dgamma=gnw, dbeta=gnb)
+        else:
+            if pool == "mean":
+                dy = torch.zeros(S, N, d, device=dev)
+                dy[:, 1:] = (dout / (N - 1)).unsqueeze(1)
+                dy = dy.view(M, d)
+            else:
+                dy = dout.reshape(M, d)
+            dx = torch.empty(M, d, device=dev)
+            dx16 = torch.empty(M, d, dtype=BF16, device=dev)
+            ops.layernorm_bwd(dy, x, nw, mean, rstd, dx_f32=dx, dx_bf16=dx16, dgamma=gnw, dbeta=gnb)
+        for i in reversed(range(n_blocks)):
+            bp = BlockParams(params[13 * i:13 * (i + 1)])
+            bg = BlockParams(gz[13 * i:13 * (i + 1)])
+            dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i])
+            ctx.saved[i] = None
+            if BLOCK_DONE_HOOK is not None:
+                BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])
+        dtok = dx.view(S, N, d) if ctx.needs_input_grad[0] else None
+        return (dtok, None, None, None, None, *grads)
+
+
+def encoder_apply(tokens, block_params, norm_w, norm_b, H, eps, pool):
+    flat = []
+    for bp in block_params:
+        flat.extend(bp)
+    return EncoderFn.apply(tokens, H, eps, pool, len(block_params), *flat, norm_w, norm_b)

@@ -1,0 +1,203 @@
+"""autograd.Function shells around the HIP schedules (hand-written backward passes; no autograd tracing inside).
+
+  TokensFn       patch-embed GEMM (+bias +interpolated pos-embed, rows scattered past CLS) + CLS fill [+ keep-gather]
+  LinearFn       y = x W^T (+ b): fp32 in/out, bf16 MFMA operands               (decoder_embed / decoder_pred)
+  MlpBnReluFn    Linear(no bias) -> BatchNorm1d(train) -> ReLU -> Linear(no bias) (projector / predictor chunk)
+  BTLossFn       BarlowTwinsLoss.forward_loss with global-batch-exact BN / cross-correlation
+"""
+import torch
+
+from . import dist as sdist
+from . import ops
+from .engine import BF16_WEIGHTS, _wgrad, grad_target
+
+BF16, F32 = torch.bfloat16, torch.float32
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+class TokensFn(torch.autograd.Function):
+    """imgs [S,1,F,T] -> tokens [S, 1+L(or keep), d] fp32 (prepare_tokens, models/mae.py:349-365).
+    Patch projection and positional table are frozen in the reference (models/mae.py:190-192,202), so the only
+    gradient is the CLS token's.  ids_keep [S, keep] int32 (or None) applies random_masking's keep-gather."""
+
+    @staticmethod
+    def forward(ctx, imgs, cls_token, w_pe, b_pe, pos, ids_keep):
+        S, _, F_, T_ = imgs.shape
+        d = w_pe.shape[0]
+        ph, pw = w_pe.shape[-2:]
+        L = (F_ // ph) * (T_ // pw)
+        dev = imgs.device
+        patches = torch.empty(S * L, ph * pw, dtype=BF16, device=dev)
+        ops.patchify_bf16(imgs.contiguous(), patches, ph, pw)
+        tok = torch.empty(S, 1 + L, d, device=dev)
+        pos2 = pos.reshape(1 + L, d)
+        ops.gemm(patches, BF16_WEIGHTS.get(w_pe), bias=b_pe.detach(), residual=pos2[1:], res_mod=L, row_group=L,
+                 out_f32=tok.view(S * (1 + L), d))
+        ops.fill_cls(tok, S, (1 + L) * d, d, cls_token.detach().reshape(-1), pos2[0])
+        if ids_keep is not None:
+            keep = ids_keep.shape[1]
+            out = torch.empty(S, 1 + keep, d, device=dev)
+            out[:, 0] = tok[:, 0]
+            ops.gather_rows(tok, (1 + L) * d, 1, ids_keep, out, (1 + keep) * d, 1, S, d)
+            tok = out
+        ctx.shape = tok.shape
+        ctx.cls_param = cls_token
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        S, N, d = ctx.shape
+        dcls = None
+        if ctx.needs_input_grad[1]:
+            dtok = dtok.contiguous()
+            buf, ret = grad_target(ctx.cls_param)
+            ops.cls_grad(dtok, S, N * d, d, buf.view(-1))
+            dcls = ret
+        return None, dcls, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        x16 = ops.cast_bf16(x2)
+        out = torch.empty(x2.shape[0], weight.shape[0], device=x.device)
+        ops.gemm(x16, BF16_WEIGHTS.get(weight), bias=bias.detach() if bias is not None else None, out_f32=out)
+        ctx.save_for_backward(x16, weight, bias)
+        ctx.xshape = x.shape
+        return out.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, weight, bias = ctx.saved_tensors
+        dy16 = ops.cast_bf16(dy.reshape(-1, dy.shape[-1]).contiguous())
+        dwb, dw = grad_target(weight)
+        _wgrad(dy16, x16, dwb)
+        db = None
+        if bias is not None:
+            dbb, db = grad_target(bias)
+            ops.colsum_bf16(dy16, dbb, accumulate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x16.shape[0], weight.shape[1], device=dy.device)
+            ops.gemm(dy16, BF16_WEIGHTS.get(weight), b_kmajor=False, out_f32=dx)
+            dx = dx.view(ctx.xshape)
+        return dx, dw, db
+
+
+def _bn_forward_stats(h, eps, running_mean, running_var):
+    """Local (mean, M2) -> all-gather -> combined mean / rstd (+ running buffers)."""
+    B, Cn = h.shape
+    dev = h.device
+    stats = torch.empty(2, Cn, device=dev)
+    ops.bn_colstats(h, stats[0], stats[1])
+    allst = sdist.all_gather_rows(stats)
+    mean, rstd = torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)
+    ops.bn_finalize(allst.contiguous(), B, eps, BN_MOMENTUM, mean, rstd, running_mean, running_var)
+    return mean, rstd
+
+
+class MlpBnReluFn(torch.autograd.Function):
+    """One crop chunk through Linear(nb) -> BN1d(train, affine) -> ReLU -> Linear(nb)  (model.py:16-23,39-45).
+    With a process group the BN is a SyncBN over the global chunk (utils/utils.py:411)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, gamma, beta, w1, running_mean, running_var):
+        B = x.shape[0]
+        dev = x.device
+        x16 = ops.cast_bf16(x.contiguous())
+        h = torch.empty(B, w0.shape[0], device=dev)
+        ops.gemm(x16, BF16_WEIGHTS.get(w0), out_f32=h)
+        mean, rstd = _bn_forward_stats(h, BN_EPS, running_mean, running_var)
+        a = torch.empty(B, w0.shape[0], dtype=BF16, device=dev)
+        ops.bn_apply(h, mean, rstd, gamma.detach(), beta.detach(), True, y_bf16=a)
+        z = torch.empty(B, w1.shape[0], device=dev)
+        ops.gemm(a, BF16_WEIGHTS.get(w1), out_f32=z)
+        ctx.save_for_backward(x16, h, mean, rstd, a, w0, gamma, beta, w1)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x16, h, mean, rstd, a, w0, gamma, beta, w1 = ctx.saved_tensors
+        B, Hd = h.shape
+        dev = h.device
+        W = sdist.get_world_size()
+        dz16 = ops.cast_bf16(dz.contiguous())
+        dw1b, dw1 = grad_target(w1)
+        _wgrad(dz16, a, dw1b)
+        da = torch.empty(B, Hd, dtype=BF16, device=dev)
+        ops.gemm(dz16, BF16_WEIGHTS.get(w1), b_kmajor=False, out_bf16=da)
+        s = torch.empty(2, Hd, device=dev)
+        ops.bn_bwd_stats(da, h, mean, rstd, gamma, beta, True, s[0], s[1])
+        dgb, dgamma = grad_target(gamma)                    # local contributions (summed over ranks with the other grads)
+        dbb, dbeta = grad_target(beta)
+        ops.axpy(dbb, s[0])
+        ops.axpy(dgb, s[1])
+        sdist.all_reduce_sum_(s)
+        dh = torch.empty(B, Hd, dtype=BF16, device=dev)
+        ops.bn_bwd_apply(da, h, mean, rstd, gamma, beta, True, s[0], s[1], 1.0 / (B * W), dx_bf16=dh)
+        dw0b, dw0 = grad_target(w0)
+        _wgrad(dh, x16, dw0b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, w0.shape[1], device=dev)
+            ops.gemm(dh, BF16_WEIGHTS.get(w0), b_kmajor=False, out_f32=dx)
+        return dx, dw0, dgamma, dbeta, dw1, None, None
+
+
+class BTLossFn(torch.autograd.Function):
+    """forward_loss(z1, z2) (utils/loss.py:15-30), fp32.  Data-parallel semantics: BN statistics and the
+    cross-correlation are those of the GLOBAL batch; `literal_ddp=True` reproduces the reference's
+    per-rank BN + division by the local batch + SUM all-reduce instead."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, alpha, lmbda, hsic, running_mean, running_var, literal_ddp):
+        B, D = z1.shape
+        dev = z1.device
+        W = sdist.get_world_size()
+        z1, z2 = z1.contiguous().float(), z2.contiguous().float()
+        norm, stats = [], []
+        for z in (z1, z2):                                   # bn(z1) then bn(z2): running stats see both, in this order
+            if literal_ddp and W > 1:
+                st = torch.empty(2, D, device=dev)
+                ops.bn_colstats(z, st[0], st[1])
+                mean, rstd = torch.empty(D, device=dev), torch.empty(D, device=dev)
+                ops.bn_finalize(st.unsqueeze(0), B, BN_EPS, BN_MOMENTUM, mean, rstd, running_mean, running_var)
+            else:
+                mean, rstd = _bn_forward_stats(z, BN_EPS, running_mean, running_var)
+            zn = torch.empty(B, D, device=dev)
+            ops.bn_apply(z, mean, rstd, None, None, False, y_f32=zn)
+            norm.append(zn)
+            stats.append((mean, rstd))
+        n_eff = B if (literal_ddp or W == 1) else B * W
+        c = torch.empty(D, D, device=dev)
+        ops.matmul_f32(norm[0], norm[1], c, trans_a=True, alpha=1.0 / n_eff)
+        sdist.all_reduce_sum_(c)                             # utils/loss.py:20-21
+        loss = torch.empty(1, device=dev)
+        G = torch.empty(D, D, device=dev)
+        ops.bt_loss_grad(c, alpha, lmbda, hsic, loss, G)
+        ctx.save_for_backward(z1, z2, norm[0], norm[1], stats[0][0], stats[0][1], stats[1][0], stats[1][1], G)
+        ctx.cfg = (n_eff, literal_ddp and W > 1)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z1, z2, z1n, z2n, m1, r1, m2, r2, G = ctx.saved_tensors
+        n_eff, local_bn = ctx.cfg
+        B, D = z1.shape
+        dev = z1.device
+        dz1n, dz2n = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
+        ops.matmul_f32(z2n, G, dz1n, trans_b=True, alpha=1.0 / n_eff)   # dz1n = z2n G^T / n
+        ops.matmul_f32(z1n, G, dz2n, alpha=1.0 / n_eff)                  # dz2n = z1n G   / n
+        scale = dloss.reshape(1).float().contiguous()
+        outs = []
+        for z, dzn, mean, rstd in ((z1, dz1n, m1, r1), (z2, dz2n, m2, r2)):
+            s = torch.empty(2, D, device=dev)
+            ops.bn_bwd_stats(dzn, z, mean, rstd, None, None, False, s[0], s[1])
+            if not local_bn:
+                sdist.all_reduce_sum_(s)
+            dz = torch.empty(B, D, device=dev)
+            ops.bn_bwd_apply(dzn, z, mean, rstd, None, None, False, s[0], s[1], 1.0 / (B if local_bn else n_eff), out_scale=scale,
+                             dx_f32=dz)
+            outs.append(dz)
+        return outs[0], outs[1], None, None, None, None, None, None

@@ -1,0 +1,273 @@
+"""MaskedAutoencoderViT on the MI355X engine -- same constructor, attribute names, state_dict keys and forward
+signature as the reference's models/mae.py:166-469, so checkpoints and call sites carry over unchanged.
+
+The nn.Module tree below only *owns parameters* (identical names / shapes / init families as the reference);
+no submodule's forward is ever called.  Compute is the explicit HIP schedule in engine.py / functional.py.
+Not provided (out of this path's scope): ConvStem (`vitc_*`), learned positional embedding,
+norm_pix_loss, forward_attn / forward_viz.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .engine import encoder_apply
+from .pos_embed import get_2d_sincos_pos_embed, get_sinusoid_encoding_table, interpolate_pos_encoding
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (list, tuple)) else (x, x)
+
+
+class PatchEmbed(nn.Module):
+    """Parameter holder for the 16x16/16 patch projection (models/mae.py:25-43): runs as patchify + MFMA GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size, self.patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+
+class AttentionKBiasZero(nn.Module):
+    """Parameter holder (models/mae.py:102-141): qkv without bias + separate q/v biases, k-bias fixed at zero."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=True):
+        super().__init__()
+        assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    """timm.models.vision_transformer.Mlp parameter layout: fc1 -> GELU(erf) -> fc2."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class BlockKBiasZero(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=True, norm_layer=nn.LayerNorm, **_):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = AttentionKBiasZero(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def engine_params(self):
+        a, m = self.attn, self.mlp
+        return (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight, a.proj.bias,
+                self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+
+
+class MaskedAutoencoderViT(nn.Module):
+    def __init__(self, img_size=(64, 96), patch_size=(16, 16), in_chans=1,
+                 embed_dim=768, depth=12, num_heads=12, conv_stem=False,
+                 use_decoder=False, use_learned_pos_embd=False,
+                 decoder_embed_dim=384, decoder_depth=4, decoder_num_heads=6,
+                 mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False,
+                 block_cls=BlockKBiasZero, use_2d_dec_pos_embd=False,
+                 drop_path_rate=0.):
+        super().__init__()
+        if conv_stem:
+            raise NotImplementedError("ConvStem (vitc_*) encoders are outside the MI355X hot path (SURVEY.md §2)")
+        if use_learned_pos_embd or norm_pix_loss or drop_path_rate:
+            raise NotImplementedError("learned pos-embed / norm_pix_loss / drop_path are not on the MI355X hot path")
+        if in_chans != 1:
+            raise NotImplementedError("audio spectrogram input only (in_chans=1)")
+        if (embed_dim // num_heads) != 64 or (use_decoder and decoder_embed_dim // decoder_num_heads != 64):
+            raise NotImplementedError("the fused attention kernel is specialised for head_dim 64 (all reference ViT sizes)")
+        self.img_size, self.in_chans, self.embed_dim = tuple(img_size), in_chans, embed_dim
+        self.conv_stem, self.use_decoder, self.use_learned_pos_embd = conv_stem, use_decoder, use_learned_pos_embd
+        self.num_heads, self.decoder_num_heads = num_heads, decoder_num_heads
+        self.ln_eps = norm_layer(8).eps
+
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        for param in self.patch_embed.parameters():      # random patch projection, frozen (models/mae.py:190-192)
+            param.requires_grad = False
+        total_patches = self.patch_embed.num_patches + 1
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, total_patches, embed_dim), requires_grad=False)
+        self.blocks = nn.ModuleList([block_cls(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                     for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        if use_decoder:
+            self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+            self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+            self.decoder_pos_embed = nn.Parameter(torch.zeros(1, total_patches, decoder_embed_dim), requires_grad=False)
+            self.decoder_blocks = nn.ModuleList([block_cls(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True,
+                                                           norm_layer=norm_layer) for _ in range(decoder_depth)])
+            self.decoder_norm = norm_layer(decoder_embed_dim)
+            self.decoder_pred = nn.Linear(decoder_embed_dim, self.img_patch_dim(), bias=True)
+        self.norm_pix_loss = norm_pix_loss
+        self._pos_cache = {}
+        self.initialize_weights(use_2d_dec_pos_embd)
+
+    # ------------------------------------------------------------------ geometry helpers (models/mae.py:232-240)
+    def patch_size(self):
+        return self.patch_embed.patch_size
+
+    def grid_size(self):
+        return self.patch_embed.grid_size
+
+    def img_patch_dim(self):
+        ps = self.patch_size()
+        return ps[0] * ps[1] * self.in_chans
+
+    # ------------------------------------------------------------------ init (models/mae.py:242-279)
+    def initialize_weights(self, use_2d_dec_pos_embd=False):
+        pos = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], self.grid_size())
+        self.pos_embed.data.copy_(torch.from_numpy(pos).float().unsqueeze(0))
+        if self.use_decoder:
+            if use_2d_dec_pos_embd:
+                dpos = get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], self.grid_size())
+            else:
+                dpos = get_sinusoid_encoding_table(self.grid_size()[0] * self.grid_size()[1], self.decoder_pos_embed.shape[-1])
+            self.decoder_pos_embed.data.copy_(torch.from_numpy(dpos).float().unsqueeze(0))
+        w = self.patch_embed.proj.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        torch.nn.init.normal_(self.cls_token, std=.02)
+        if self.use_decoder:
+            torch.nn.init.normal_(self.mask_token, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ positional table per input width (cached)
+    def interpolate_pos_encoding(self, freq_bins, frames):
+        key = (freq_bins, frames, self.pos_embed.device, self.pos_embed._version)
+        if key not in self._pos_cache:
+            self._pos_cache.clear()
+            pos = interpolate_pos_encoding(self.pos_embed.detach().cpu().numpy(), self.grid_size(), freq_bins, frames,
+                                           self.patch_size())
+            self._pos_cache[key] = torch.from_numpy(pos).float().to(self.pos_embed.device).contiguous()
+        return self._pos_cache[key]
+
+    def patchify(self, imgs):
+        ph, pw = self.patch_size()
+        h, w = self.grid_size()
+        x = imgs.reshape(shape=(imgs.shape[0], self.in_chans, h, ph, w, pw))
+        x = torch.einsum('nchpwq->nhwpqc', x)
+        return x.reshape(shape=(imgs.shape[0], h * w, self.img_patch_dim()))
+
+    # ------------------------------------------------------------------ masking indices (models/mae.py:309-347)
+    def masking_indices(self, N, L, mask_ratio, device, noise=None):
+        """Returns (ids_keep int32 [N, keep], mask [N, L], ids_restore [N, L]).  Index bookkeeping only (argsort of the
+        per-sample noise); the token gather itself is the HIP kernel behind TokensFn."""
+        if isinstance(mask_ratio, (torch.Tensor, np.ndarray, list, tuple)):
+            mask_in = torch.as_tensor(mask_ratio, device=device).detach()
+            ids_shuffle = torch.argsort(mask_in.reshape(N, -1), dim=1)
+            len_keep = int((mask_in[0] == 0).sum())
+        else:
+            len_keep = int(L * (1 - mask_ratio))
+            if noise is None:
+                noise = torch.rand(N, L, device=device)
+            ids_shuffle = torch.argsort(noise, dim=1)
+        ids_restore = torch.argsort(ids_shuffle, dim=1)
+        ids_keep = ids_shuffle[:, :len_keep]
+        mask = torch.ones([N, L], device=device)
+        mask[:, :len_keep] = 0
+        mask = torch.gather(mask, dim=1, index=ids_restore)
+        return ids_keep.to(torch.int32).contiguous(), mask, ids_restore
+
+    # ------------------------------------------------------------------ forward (models/mae.py:349-469)
+    def prepare_tokens(self, x, mask_ratio, noise=None):
+        B, nc, w, h = x.shape
+        L = (w // self.patch_size()[0]) * (h // self.patch_size()[1])
+        pos = self.interpolate_pos_encoding(w, h)
+        no_mask = not isinstance(mask_ratio, (torch.Tensor, np.ndarray, list, tuple)) and mask_ratio == 0
+        if no_mask:
+            ids_keep, mask = None, torch.zeros([B, L], device=x.device)
+            ids_restore = torch.arange(L, device=x.device).to(torch.int)
+        else:
+            ids_keep, mask, ids_restore = self.masking_indices(B, L, mask_ratio, x.device, noise)
+        tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep)
+        return tok, mask, ids_restore
+
+    def _run_blocks(self, tok, blocks, norm, heads, pool):
+        return encoder_apply(tok, [b.engine_params() for b in blocks], norm.weight, norm.bias, heads, self.ln_eps, pool)
+
+    def forward_encoder(self, x, mask_ratio, noise=None):
+        tok, mask, ids_restore = self.prepare_tokens(x, mask_ratio, noise)
+        return self._run_blocks(tok, self.blocks, self.norm, self.num_heads, "all"), mask, ids_restore
+
+    def forward_decoder(self, x, ids_restore):
+        x = Fn.LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
+        mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] + 1 - x.shape[1], 1)
+        x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
+        x_ = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))   # un-shuffle (data movement)
+        x = torch.cat([x[:, :1, :], x_], dim=1) + self.decoder_pos_embed
+        x = self._run_blocks(x.contiguous(), self.decoder_blocks, self.decoder_norm, self.decoder_num_heads, "all")
+        x = Fn.LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
+        return x[:, 1:, :]
+
+    def forward_loss(self, imgs, pred, mask):
+        target = self.patchify(imgs)
+        loss = ((pred - target) ** 2).mean(dim=-1)
+        return (loss * mask).sum() / mask.sum()
+
+    def forward(self, imgs, mask_ratio=0, mean_pool=False, return_all=False, masked_recon=False, noise=None):
+        if masked_recon or return_all:
+            x, mask, ids_restore = self.forward_encoder(imgs, mask_ratio, noise)
+            if return_all:
+                latent = x
+            elif mean_pool:
+                latent = torch.mean(x[:, 1:], dim=1).contiguous()
+            else:
+                latent = x[:, 0].contiguous()
+            if masked_recon:
+                pred = self.forward_decoder(x, ids_restore)
+                return latent, self.forward_loss(imgs, pred, mask)
+            return latent
+        tok, _, _ = self.prepare_tokens(imgs, mask_ratio, noise)
+        return self._run_blocks(tok, self.blocks, self.norm, self.num_heads, "mean" if mean_pool else "cls")
+
+
+def _vit(patch_size, embed_dim, depth, num_heads, **kwargs):
+    return MaskedAutoencoderViT(patch_size=patch_size, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_base_patchX(patch_size, **kwargs):
+    return _vit(patch_size, 768, 12, 12, decoder_embed_dim=384, decoder_depth=4, decoder_num_heads=6, **kwargs)
+
+
+def mae_vit_small_patchX(patch_size, **kwargs):
+    return _vit(patch_size, 384, 12, 6, **kwargs)
+
+
+def mae_vit_tiny_patchX(patch_size, **kwargs):
+    return _vit(patch_size, 192, 12, 3, **kwargs)
+
+
+def mae_vit_large_patchX(patch_size, **kwargs):
+    """Not in the reference: BASELINE config 5's ViT-L (d=1024, 24 layers, 16 heads)."""
+    return _vit(patch_size, 1024, 24, 16, decoder_embed_dim=384, decoder_depth=4, decoder_num_heads=6, **kwargs)
+
+
+def get_mae_vit(size='base', patch_size=None, c=False, **kwargs):
+    if patch_size is None:
+        patch_size = [16, 16]
+    if c:
+        raise NotImplementedError("ConvStem (vitc_*) encoders are outside the MI355X hot path (SURVEY.md §2)")
+    table = {'base': mae_vit_base_patchX, 'small': mae_vit_small_patchX, 'tiny': mae_vit_tiny_patchX, 'large': mae_vit_large_patchX}
+    if size not in table:
+        raise NotImplementedError(f'Size {size} is not supported')
+    return table[size](patch_size, **kwargs)

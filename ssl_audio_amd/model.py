@@ -1,0 +1,102 @@
+"""Model-side API surface of the reference's model.py (ModelWrapper :57-103, ViT :107-127, BarlowTwinsHead :11-31,
+BarlowTwinsPredictor :34-53) on the MI355X engine.  Same constructor arguments, attributes and state_dict keys.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import mae
+
+
+def _chunked_mlp(x, ncrops, seq):
+    """Shared by head and predictor: the MLP (with its BatchNorm statistics) is applied per crop chunk."""
+    lin0, bn, _, lin1 = seq[0], seq[1], seq[2], seq[3]
+    outs = []
+    for _x in x.chunk(ncrops):
+        outs.append(Fn.MlpBnReluFn.apply(_x, lin0.weight, bn.weight, bn.bias, lin1.weight, bn.running_mean, bn.running_var))
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+
+class BarlowTwinsHead(nn.Module):
+    def __init__(self, cfg, in_dim):
+        super().__init__()
+        self.cfg = cfg
+        if self.cfg.projector_n_hidden_layers != 1:
+            raise NotImplementedError("the fused projector covers the reference default: one hidden layer (Linear-BN-ReLU-Linear)")
+        sizes = [in_dim] + self.cfg.projector_n_hidden_layers * [self.cfg.projector_hidden_dim] + [self.cfg.projector_out_dim]
+        layers = []
+        for i in range(len(sizes) - 2):
+            layers.append(nn.Linear(sizes[i], sizes[i + 1], bias=False))
+            layers.append(nn.BatchNorm1d(sizes[i + 1]))
+            layers.append(nn.ReLU(inplace=True))
+        layers.append(nn.Linear(sizes[-2], sizes[-1], bias=False))
+        self.projector = nn.Sequential(*layers)     # parameter holder; compute = Fn.MlpBnReluFn
+
+    def forward(self, x, ncrops=2):
+        return _chunked_mlp(x, ncrops, self.projector)
+
+
+class BarlowTwinsPredictor(nn.Module):
+    def __init__(self, in_dim, use=True):
+        super().__init__()
+        self.predictor = nn.Identity()
+        if use:
+            self.predictor = nn.Sequential(
+                nn.Linear(in_dim, in_dim, bias=False),
+                nn.BatchNorm1d(in_dim),
+                nn.ReLU(inplace=True),
+                nn.Linear(in_dim, in_dim, bias=False),
+            )
+
+    def forward(self, x, ncrops=2):
+        if isinstance(self.predictor, nn.Identity):
+            return x
+        return _chunked_mlp(x, ncrops, self.predictor)
+
+
+class ModelWrapper(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self._setup_model()
+
+    def _setup_model(self):
+        if 'vit' in self.cfg.model_type:
+            conv_stem_bool = self.cfg.model_type.split('_')[0] == 'vitc'
+            self.encoder = ViT(
+                dataset=self.cfg.dataset,
+                size=self.cfg.model_type.split('_')[-1],
+                patch_size=self.cfg.patch_size,
+                c=conv_stem_bool,
+                use_learned_pos_embd=self.cfg.use_learned_pos_embd,
+                use_mean_pool=self.cfg.use_mean_pool,
+                use_decoder=self.cfg.masked_recon,
+            )
+        else:
+            # resnet* / audiontt encoders run on stock ops in the reference and are not part of this hot path
+            raise NotImplementedError(f'Model type {self.cfg.model_type} is not supported on the MI355X hot path')
+        self.feature_dim = self.encoder.embed_dim
+
+    def forward(self, x, mask_ratio=0, masked_recon=False):
+        return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon)
+
+
+class ViT(nn.Module):
+    def __init__(self, dataset='fsd50k', size='base', patch_size=None, c=True,
+                 use_learned_pos_embd=False, use_mean_pool=False, use_decoder=False, img_size=None):
+        super().__init__()
+        if patch_size is None:
+            patch_size = [16, 16]
+        if dataset == 'cifar10':
+            raise NotImplementedError("the cifar10 sanity path is out of scope")
+        kw = dict(use_learned_pos_embd=use_learned_pos_embd, use_decoder=use_decoder)
+        if img_size is not None:          # config 5 needs the constructor grid; the reference never passes it
+            kw["img_size"] = img_size
+        self.encoder = mae.get_mae_vit(size, patch_size, c, **kw)
+        self.embed_dim = self.encoder.embed_dim
+        self.use_mean_pool = use_mean_pool
+
+    def forward(self, x, mask_ratio=0, masked_recon=False):
+        return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon, mean_pool=self.use_mean_pool)

@@ -12,6 +12,7 @@ from ._lib import SaGemmArgs, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end event, flops, layout) per GEMM launch
 
 
 def _stream():
@@ -66,7 +67,16 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     if out_bf16 is not None:
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
     a.row_group, a.split_k, a.accumulate = row_group, split_k, int(accumulate)
+    if GEMM_PROFILE is None:
+        check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
+        return
+    # bench.py's roofline leg: HIP events on the launch stream around this launch (flops = 2*M*N*K, algorithmic)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
+    e1.record()
+    kind = ("NT" if b_kmajor else "NN") if a_kmajor else ("TT" if b_kmajor else "TN")
+    GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else "")))
 
 
 def pick_split_k(M, N, K, cu_count=256):
@@ -151,11 +161,18 @@ def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s1, s2):
                                 _p(beta), int(relu), _p(s1), _p(s2), _stream()), "sa_bn_bwd_stats")
 
 
-def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s1, s2, inv_n, *, dx_f32=None, dx_bf16=None):
+def bn_finalize(stats, rows_per_rank, eps, momentum, mean, rstd, running_mean=None, running_var=None):
+    """stats: [W, 2, C] per-rank (mean, M2)."""
+    Wn, _, Cn = stats.shape
+    check(lib().sa_bn_finalize(_p(_req(stats, F32, "stats")), Wn, rows_per_rank, Cn, float(eps), float(momentum), _p(mean), _p(rstd),
+                               _p(running_mean), _p(running_var), _stream()), "sa_bn_finalize")
+
+
+def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s1, s2, inv_n, *, out_scale=None, dx_f32=None, dx_bf16=None):
     B, Cn, ld = _rows(_req(x, F32, "x"), "x")
     dxo = dx_f32 if dx_f32 is not None else dx_bf16
     check(lib().sa_bn_bwd_apply(_p(dy), int(dy.dtype == BF16), _rows(dy, "dy")[2], _p(x), ld, B, Cn, _p(mean), _p(rstd), _p(gamma),
-                                _p(beta), int(relu), _p(s1), _p(s2), float(inv_n), _p(dx_f32), _p(dx_bf16), _rows(dxo, "dx")[2],
+                                _p(beta), int(relu), _p(s1), _p(s2), float(inv_n), _p(out_scale), _p(dx_f32), _p(dx_bf16), _rows(dxo, "dx")[2],
                                 _stream()), "sa_bn_bwd_apply")
 
 
@@ -188,6 +205,10 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf
 
 def ema_update(target, online, beta):
     check(lib().sa_ema_update(_p(target), _p(online), target.numel(), float(beta), _stream()), "sa_ema_update")
+
+
+def axpy(y, x, a=1.0):
+    check(lib().sa_axpy_f32(_p(_req(y, F32, "y")), _p(_req(x, F32, "x")), y.numel(), float(a), _stream()), "sa_axpy_f32")
 
 
 # ------------------------------------------------------------------------------------------------ frontend / augmentation

@@ -1,0 +1,257 @@
+"""The pre-training step of the hot path, MI355X-first: the counterpart of train_one_epoch
+(main_bt_byol.py:40-166) and of main.py:86-119, with everything that the reference leaves on the host moved
+onto the GPU and everything launch-bound flattened:
+
+  waveforms (HBM) --sa_logmel_fwd--> ring of normalised log-mels --sa_augment_views--> 2 views
+     --> encoder + projector (engine.py) --> Barlow Twins loss (global-batch exact) --> backward
+     --> gradient all-reduce per transformer block on a side stream (RCCL) overlapped with the remaining backward
+     --> ONE fused AdamW launch per weight-decay group over flat fp32 state (+ bf16 weight refresh in the same pass)
+     --> (BYOL-ish variant) ONE EMA launch over the flat parameter buffer.
+
+Parameters, gradients and Adam moments live in flat buffers (`FlatState`); the nn.Module parameters are views
+into them, so state_dict()/load_state_dict() keep the reference's key names.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import dist as sdist
+from . import engine, ops
+from .augmentations import BatchedPairAugment, NormalizeBatch
+from .frontend import MelSpectrogram
+from .loss import BarlowTwinsLoss
+from .model import BarlowTwinsHead, BarlowTwinsPredictor, ModelWrapper
+from .utils import MultiCropWrapper
+
+AUDIOSET_STATS = (-0.8294, 4.6230)   # main_bt_byol.py:288
+
+
+class FlatState:
+    """Flat fp32 parameter / gradient / Adam-moment buffers for a set of modules.
+
+    Layout: [decayed params | un-decayed params | frozen params], each parameter padded to 8 elements so every view
+    is 32-byte aligned.  get_param_groups' rule (utils/utils.py:136-147): no decay on '.bias' names and 1-D tensors.
+    """
+
+    def __init__(self, named_params, device):
+        decay, nodecay, frozen = [], [], []
+        for name, p in named_params:
+            if not p.requires_grad:
+                frozen.append((name, p))
+            elif name.endswith(".bias") or p.dim() == 1:
+                nodecay.append((name, p))
+            else:
+                decay.append((name, p))
+        self.order = decay + nodecay + frozen
+        pad8 = lambda n: (n + 7) // 8 * 8
+        self.n_decay = sum(pad8(p.numel()) for _, p in decay)
+        self.n_train = self.n_decay + sum(pad8(p.numel()) for _, p in nodecay)
+        total = self.n_train + sum(pad8(p.numel()) for _, p in frozen)
+        self.params = torch.zeros(total, device=device)
+        self.params_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=device)
+        self.grads = torch.zeros(self.n_train, device=device)
+        self.m = torch.zeros(self.n_train, device=device)
+        self.v = torch.zeros(self.n_train, device=device)
+        self.offsets = {}
+        off = 0
+        for name, p in self.order:
+            n = p.numel()
+            self.params[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.params[off:off + n].view(p.shape)
+            self.offsets[name] = (off, n)
+            if off < self.n_train:
+                engine.GRAD_SINK[id(p)] = self.grads[off:off + n].view(p.shape)
+            off += pad8(n)
+        ops.cast_bf16(self.params, self.params_bf16)
+        self.bind_bf16()
+        self.step_count = 0
+
+    def bind_bf16(self):
+        """Point the engine's bf16 weight cache at views of the flat bf16 buffer (kept fresh by the AdamW kernel)."""
+        for name, p in self.order:
+            off, n = self.offsets[name]
+            w = self.params_bf16[off:off + n]
+            w = w.view(p.shape[0], -1) if p.dim() > 1 else w
+            engine.BF16_WEIGHTS.pin(p, w)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def adamw(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        self.step_count += 1
+        nd, nt = self.n_decay, self.n_train
+        if nd:
+            ops.adamw_step(self.params[:nd], self.grads[:nd], self.m[:nd], self.v[:nd], lr, betas[0], betas[1], eps, wd, self.step_count,
+                           grad_scale, self.params_bf16[:nd])
+        if nt > nd:
+            ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr, betas[0], betas[1], eps, 0.0,
+                           self.step_count, grad_scale, self.params_bf16[nd:nt])
+
+    def ema_from(self, other, beta):
+        """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch."""
+        assert self.params.numel() == other.params.numel()
+        ops.ema_update(self.params, other.params, beta)
+        ops.cast_bf16(self.params, self.params_bf16)
+
+
+class GradSync:
+    """Gradient SUM all-reduce over ranks, bucketed per transformer block and overlapped with backward on a side
+    HIP stream (collective site C3).  Buckets are contiguous ranges of FlatState.grads."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20):
+        self.flat = flat
+        self.world = sdist.get_world_size()
+        self.stream = torch.cuda.Stream() if (self.world > 1 and flat.grads.is_cuda) else None
+        self.pending = []
+        self.bucket_bytes = bucket_bytes
+        self._ready_ranges = []
+
+    def block_done(self, params):
+        """engine.BLOCK_DONE_HOOK: the gradients of `params` are final -> reduce their flat range now."""
+        if self.world == 1:
+            return
+        lo, hi = None, None
+        for p in params:
+            g = engine.GRAD_SINK.get(id(p))
+            if g is None:
+                continue
+            a = (g.data_ptr() - self.flat.grads.data_ptr()) // 4
+            lo = a if lo is None else min(lo, a)
+            hi = a + g.numel() if hi is None else max(hi, a + g.numel())
+        if lo is not None:
+            self._launch(lo, hi)
+
+    def _launch(self, lo, hi):
+        self._ready_ranges.append((lo, hi))
+        view = self.flat.grads[lo:hi]
+        if self.stream is None:
+            sdist.all_reduce_sum_(view)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            self.pending.append(torch.distributed.all_reduce(view, async_op=True))
+
+    def finish(self):
+        """Reduce whatever no block hook covered (head, cls token, final norm, ...) and join the side stream."""
+        if self.world == 1:
+            return
+        n = self.flat.n_train
+        gaps, cur = [], 0
+        for lo, hi in sorted(self._ready_ranges) + [(n, n)]:      # complement of what the block hooks already reduced
+            if lo > cur:
+                gaps.append((cur, lo))
+            cur = max(cur, hi)
+        for lo, hi in gaps:
+            self._launch(lo, hi)
+        for w in self.pending:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.pending.clear()
+        self._ready_ranges.clear()
+
+
+class BarlowTwinsTrainer:
+    """One object = the whole step.  mode='bt': single network, two views, one loss term (main.py:86-119, BASELINE
+    configs 2-3).  mode='byol': online (+predictor) / EMA target, two cross terms (main_bt_byol.py --stop_gradient
+    --predictor, BASELINE config 4)."""
+
+    def __init__(self, cfg, device, mode="bt", batch_per_rank=None, clip_samples=160000, seed=0, from_waveform=True,
+                 ema_beta=0.99):
+        self.cfg, self.device, self.mode = cfg, device, mode
+        self.world = sdist.get_world_size()
+        self.B = batch_per_rank or cfg.batch_size // self.world
+        self.clip_samples = clip_samples
+        self.from_waveform = from_waveform
+        torch.manual_seed(seed)
+        self.online = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
+        self.flat = FlatState(list(self.online.named_parameters()), device)
+        self.criterion = BarlowTwinsLoss(cfg, ncrops=2).to(device)
+        self.sync = GradSync(self.flat)
+        engine.BLOCK_DONE_HOOK = self.sync.block_done
+        self.predictor = self.target = self.flat_pred = self.flat_target = None
+        if mode == "byol":
+            self.predictor = BarlowTwinsPredictor(cfg.projector_out_dim, use=True).to(device)
+            self.flat_pred = FlatState(list(self.predictor.named_parameters()), device)
+            self.sync_pred = GradSync(self.flat_pred)
+            self.target = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
+            self.target.load_state_dict(self.online.state_dict())
+            for p in self.target.parameters():
+                p.requires_grad = False
+            self.flat_target = _FrozenFlat(self.target, self.flat, device)
+            self.ema_beta = ema_beta
+        self.frontend = MelSpectrogram(cfg.sample_rate, cfg.n_fft, cfg.win_length, cfg.hop_length, cfg.n_mels, cfg.f_min, cfg.f_max)
+        frames = self.frontend.n_frames(clip_samples) if from_waveform else cfg.crop_frames
+        self.frames = frames
+        self.augment = BatchedPairAugment(device, cfg.n_mels, cfg.crop_frames, cfg.crop_frames, cfg.mixup, cfg.RRC, cfg.RLF,
+                                          cfg.mixup_ratio, virtual_crop_scale=tuple(cfg.virtual_crop_scale), seed=seed + 1000 * sdist.get_rank())
+        self.post_norm = NormalizeBatch() if cfg.post_norm else None
+        self.lr, self.wd = cfg.lr, cfg.wd
+        self.last_loss = None
+
+    # ------------------------------------------------------------------ data path
+    def make_views(self, batch):
+        """batch: waveforms [B, L] (from_waveform) or log-mels [B, 1, F, T_any]; -> [view1, view2] each [B,1,F,crop_frames]."""
+        B = batch.shape[0]
+        slots = self.augment.next_slots(B)
+        if self.from_waveform:
+            self.frontend(batch, crop_frames=self.cfg.crop_frames, start=0, norm_stats=AUDIOSET_STATS, out=slots.view(B, 1, *slots.shape[1:]))
+        else:
+            slots.copy_(batch.view(B, *batch.shape[-2:]))
+        views = self.augment(B)
+        v1, v2 = views[0], views[1]
+        if self.post_norm is not None:
+            v1, v2 = self.post_norm(v1), self.post_norm(v2)
+        return [v1, v2]
+
+    # ------------------------------------------------------------------ one optimisation step
+    def step(self, batch):
+        cfg = self.cfg
+        views = self.make_views(batch)
+        self.flat.zero_grad()
+        if self.mode == "bt":
+            z = self.online(views, ncrops=2)
+            z1, z2 = z.chunk(2)
+            loss = self.criterion.forward_loss(z1, z2)
+        else:
+            self.flat_pred.zero_grad()
+            o = self.online(views[:2], ncrops=2)
+            o = self.predictor(o, ncrops=1)
+            with torch.no_grad():
+                t = self.target(views, ncrops=2)
+            loss = self.criterion(o, t, ngcrops_each=2)
+            self.flat_target.ema_from(self.flat, self.ema_beta)      # before the optimiser step (main_bt_byol.py:121-126)
+        loss.backward()
+        self.sync.finish()
+        self.flat.adamw(self.lr, self.wd)
+        if self.mode == "byol":
+            self.sync_pred.finish()
+            self.flat_pred.adamw(self.lr, self.wd)
+        self.last_loss = loss.detach()
+        return self.last_loss
+
+
+class _FrozenFlat:
+    """Flat parameter buffer of the EMA target with the SAME layout as the online FlatState (so EMA is one launch)."""
+
+    def __init__(self, module, like, device):
+        self.params = torch.zeros_like(like.params)
+        self.params_bf16 = torch.zeros_like(like.params_bf16)
+        named = dict(module.named_parameters())
+        for name, _ in like.order:
+            p = named[name]
+            off, n = like.offsets[name]
+            self.params[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.params[off:off + n].view(p.shape)
+            w = self.params_bf16[off:off + n]
+            engine.BF16_WEIGHTS.pin(p, w.view(p.shape[0], -1) if p.dim() > 1 else w)
+        ops.cast_bf16(self.params, self.params_bf16)
+
+    ema_from = FlatState.ema_from
+
+
+def _feature_dim(cfg):
+    return {"tiny": 192, "small": 384, "base": 768, "large": 1024}[cfg.model_type.split("_")[-1]]

@@ -228,11 +228,11 @@ def gen_augment():
 
 
 # ----------------------------------------------------------------------------- ViT (micro) + pos-embed
-def micro_vit(use_decoder=False, img_size=(64, 96), embed_dim=64, depth=2, heads=2):
+def micro_vit(use_decoder=False, img_size=(64, 96), embed_dim=128, depth=2, heads=2):
     return ref_mae.MaskedAutoencoderViT(
         img_size=img_size, patch_size=[16, 16], in_chans=1, embed_dim=embed_dim, depth=depth, num_heads=heads,
         mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_decoder=use_decoder,
-        decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=2)
+        decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=1)
 
 
 def perturb_(m, seed):
@@ -327,15 +327,15 @@ def gen_vit():
 # ----------------------------------------------------------------------------- head / predictor
 def gen_head():
     out = {}
-    cfg = cfg_ns(projector_hidden_dim=96, projector_out_dim=32, projector_n_hidden_layers=1)
+    cfg = cfg_ns(projector_hidden_dim=192, projector_out_dim=64, projector_n_hidden_layers=1)
     torch.manual_seed(0)
-    head = ref_model.BarlowTwinsHead(cfg, in_dim=48)
+    head = ref_model.BarlowTwinsHead(cfg, in_dim=128)
     with torch.no_grad():
-        head.projector[1].weight.add_(0.2 * torch.randn(96))
-        head.projector[1].bias.add_(0.2 * torch.randn(96))
+        head.projector[1].weight.add_(0.2 * torch.randn(192))
+        head.projector[1].bias.add_(0.2 * torch.randn(192))
     for k, v in head.state_dict().items():
         out["head_sd." + k] = t2n(v)
-    x = torch.randn(2 * 12, 48, requires_grad=True)
+    x = torch.randn(2 * 12, 128, requires_grad=True)
     z = head(x, ncrops=2)
     w = torch.randn_like(z)
     (z * w).sum().backward()
@@ -345,10 +345,10 @@ def gen_head():
     for k, v in head.state_dict().items():
         out["head_sd_after." + k] = t2n(v)
     torch.manual_seed(1)
-    pred = ref_model.BarlowTwinsPredictor(32, use=True)
+    pred = ref_model.BarlowTwinsPredictor(64, use=True)
     for k, v in pred.state_dict().items():
         out["pred_sd." + k] = t2n(v)
-    x = torch.randn(2 * 12, 32, requires_grad=True)
+    x = torch.randn(2 * 12, 64, requires_grad=True)
     z = pred(x, ncrops=1)
     w = torch.randn_like(z)
     (z * w).sum().backward()
@@ -375,14 +375,14 @@ def gen_step():
     """main_bt_byol.py:79-135 with --stop_gradient --predictor, and the plain two-net variant, B=8, T=96."""
     for tag, stop_grad, use_pred in [("byol", True, True), ("plain", False, False)]:
         out = {}
-        cfg = cfg_ns(projector_hidden_dim=96, projector_out_dim=32, model_type="vit_tiny", batch_size=8)
+        cfg = cfg_ns(projector_hidden_dim=192, projector_out_dim=64, model_type="vit_tiny", batch_size=8)
         ref_hp.setup_hyperparameters(cfg)
         torch.manual_seed(0)
-        online = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 64))
+        online = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 128))
         perturb_(online, 3)
-        predictor = ref_model.BarlowTwinsPredictor(32, use=use_pred)
+        predictor = ref_model.BarlowTwinsPredictor(64, use=use_pred)
         torch.manual_seed(1)
-        target = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 64))
+        target = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(cfg, 128))
         target.load_state_dict(online.state_dict())
         if stop_grad:
             for p in target.parameters():
@@ -422,10 +422,13 @@ def gen_step():
             opt.step()
         out["losses"] = np.array(losses)
         out["lr"], out["wd"] = np.array(cfg.lr), np.array(cfg.wd)
+        keep = lambda k: ("blocks.0." in k) or k.startswith("head.") or ("norm." in k and "blocks" not in k) or k.endswith("cls_token")
         for k, v in online.state_dict().items():
-            out["online_sd_after." + k] = t2n(v)
+            if keep(k):
+                out["online_sd_after." + k] = t2n(v)
         for k, v in target.state_dict().items():
-            out["target_sd_after." + k] = t2n(v)
+            if keep(k):
+                out["target_sd_after." + k] = t2n(v)
         for k, v in crit.state_dict().items():
             out["crit_sd_after." + k] = t2n(v)
         save(f"step_{tag}", **out)
@@ -455,7 +458,7 @@ def gen_misc():
     out["ema_out_w"] = t2n(a.weight)
     torch.manual_seed(0)
     online = ref_utils.MultiCropWrapper(_MicroBackbone(), ref_model.BarlowTwinsHead(
-        cfg_ns(projector_hidden_dim=96, projector_out_dim=32), 64))
+        cfg_ns(projector_hidden_dim=192, projector_out_dim=64), 128))
     groups = ref_utils.get_param_groups(online)
     names = {id(p): n for n, p in online.named_parameters()}
     out["pg_regularized"] = np.array([names[id(p)] for p in groups[0]["params"]])

@@ -29,7 +29,7 @@ def bf(x):
 
 
 def rel_err(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
@@ -145,7 +145,7 @@ def test_layernorm_strided_cls_rows(dev):
     y = torch.empty(S, D, device=dev)
     xd = x.to(dev)
     ops.layernorm_fwd(xd.view(S, N * D)[:, :D], g.to(dev), b.to(dev), 1e-6, y_f32=y)
-    assert rel_err(y, torch.nn.functional.layer_norm(x[:, 0].double(), (D,))) < 2e-6
+    assert rel_err(y, torch.nn.functional.layer_norm(x[:, 0].double(), (D,), eps=1e-6)) < 2e-6
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -1,0 +1,325 @@
+"""Module-level parity on a real MI355X: the reference-shaped classes of ssl_audio_amd (mirrors of model.py,
+utils/loss.py, utils/utils.py, augmentations.py, utils/transforms.py) against golden vectors captured from the
+reference and against the CPU oracle.  bf16 MFMA operands bound the encoder tolerances (stated per check)."""
+import random
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from ssl_audio_amd import augmentations as aug  # noqa: E402
+from ssl_audio_amd import hyperparameters as hp  # noqa: E402
+from ssl_audio_amd import mae, model, ops, transforms, utils  # noqa: E402
+from ssl_audio_amd.loss import BarlowTwinsLoss  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    ops.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev=None, dtype=torch.float32):
+    t = torch.from_numpy(np.asarray(a)).to(dtype)
+    return t.to(dev) if dev is not None else t
+
+
+def rel(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.from_numpy(np.asarray(a)).double()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.from_numpy(np.asarray(b)).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def micro_vit(dev, use_decoder=False, img_size=(64, 96)):
+    m = mae.MaskedAutoencoderViT(img_size=img_size, patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), use_decoder=use_decoder, decoder_embed_dim=64,
+                                 decoder_depth=1, decoder_num_heads=1)
+    return m.to(dev)
+
+
+def load_prefixed(module, g, prefix, dev):
+    sd = {k[len(prefix):]: T(v, dev, torch.long if "num_batches" in k else torch.float32) for k, v in g.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("tag", ["anchor", "hsic", "cfg1", "ragged"])
+def test_bt_loss_golden(dev, golden, tag):
+    """fp32 end to end: loss rel 1e-5, gradients rel 1e-4 of the reference's values."""
+    g = golden("bt_loss")
+    D = g[f"{tag}_z1"].shape[1]
+    cfg = hp.make_args(model_type="vit_tiny", projector_out_dim=D, HSIC=bool(g[f"{tag}_hsic"]))
+    crit = BarlowTwinsLoss(cfg, ncrops=2).to(dev)
+    z1, z2 = T(g[f"{tag}_z1"], dev).requires_grad_(True), T(g[f"{tag}_z2"], dev).requires_grad_(True)
+    loss = crit.forward_loss(z1, z2)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) / float(g[f"{tag}_loss"]) < 1e-5
+    assert rel(z1.grad, g[f"{tag}_dz1"]) < 1e-4 and rel(z2.grad, g[f"{tag}_dz2"]) < 1e-4
+    assert rel(crit.bn.running_mean, g[f"{tag}_running_mean"]) < 1e-5
+    assert rel(crit.bn.running_var, g[f"{tag}_running_var"]) < 1e-5
+    assert int(crit.bn.num_batches_tracked) == int(g[f"{tag}_nbt"])
+
+
+@pytest.mark.parametrize("tag", ["g1L0", "g1L1", "g2L0"])
+def test_bt_loss_forward_crops(dev, golden, tag):
+    g = golden("bt_loss")
+    cfg = hp.make_args(model_type="vit_tiny", projector_out_dim=32)
+    crit = BarlowTwinsLoss(cfg, ncrops=int(g[f"fwd_{tag}_ncrops"])).to(dev)
+    st, te = T(g[f"fwd_{tag}_student"], dev).requires_grad_(True), T(g[f"fwd_{tag}_teacher"], dev).requires_grad_(True)
+    loss = crit(st, te, ngcrops_each=int(g[f"fwd_{tag}_g"]))
+    loss.backward()
+    assert abs(float(loss) - float(g[f"fwd_{tag}_loss"])) / float(g[f"fwd_{tag}_loss"]) < 1e-5
+    assert rel(st.grad, g[f"fwd_{tag}_dstudent"]) < 1e-4 and rel(te.grad, g[f"fwd_{tag}_dteacher"]) < 1e-4
+    assert rel(crit.bn.running_var, g[f"fwd_{tag}_running_var"]) < 1e-5
+
+
+def test_off_diagonal(golden):
+    g = golden("bt_loss")
+    assert np.array_equal(utils.off_diagonal(T(g["offdiag_in"])).numpy(), g["offdiag_out"])
+
+
+# ------------------------------------------------------------------------------------------------ head / predictor
+def test_head_predictor_golden(dev, golden):
+    """bf16 GEMM operands (K = 128 / 192 / 64): outputs rel 1e-2, gradients rel 3e-2 of the fp32 reference."""
+    g = golden("head")
+    cfg = hp.make_args(model_type="vit_tiny", projector_hidden_dim=192, projector_out_dim=64)
+    head = model.BarlowTwinsHead(cfg, 128).to(dev)
+    load_prefixed(head, g, "head_sd.", dev)
+    x = T(g["head_x"], dev).requires_grad_(True)
+    z = head(x, ncrops=2)
+    assert rel(z, g["head_z"]) < 1e-2
+    (z * T(g["head_w"], dev)).sum().backward()
+    assert rel(x.grad, g["head_dx"]) < 3e-2
+    for n, p in head.named_parameters():
+        assert rel(p.grad, g["head_grad." + n]) < 3e-2, n
+    for k in ["projector.1.running_mean", "projector.1.running_var"]:
+        assert rel(head.state_dict()[k], g["head_sd_after." + k]) < 1e-2, k
+    assert int(head.state_dict()["projector.1.num_batches_tracked"]) == int(g["head_sd_after.projector.1.num_batches_tracked"])
+    pred = model.BarlowTwinsPredictor(64, use=True).to(dev)
+    load_prefixed(pred, g, "pred_sd.", dev)
+    x = T(g["pred_x"], dev).requires_grad_(True)
+    z = pred(x, ncrops=1)
+    assert rel(z, g["pred_z"]) < 1e-2
+    (z * T(g["pred_w"], dev)).sum().backward()
+    assert rel(x.grad, g["pred_dx"]) < 3e-2
+    assert model.BarlowTwinsPredictor(64, use=False)(x) is x
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("tag,T_", [("t96", 96), ("t208", 208), ("t1001", 1001)])
+def test_vit_golden(dev, golden, tag, T_):
+    """Micro ViT (d=128, 2 blocks, 2 heads) with the reference's weights: tokens are fp32-exact up to the bf16 patch
+    GEMM (rel 5e-3); latents rel 2e-2; parameter gradients rel 5e-2 (bf16 activations through 2 blocks)."""
+    g = golden("vit_micro")
+    m = micro_vit(dev)
+    load_prefixed(m, g, "sd.", dev)
+    x = T(g[f"{tag}_x"], dev)
+    np.testing.assert_allclose(m.interpolate_pos_encoding(64, T_).cpu().numpy(), g[f"{tag}_pos"], atol=2e-6)
+    tok, _, _ = m.prepare_tokens(x, 0)
+    assert rel(tok, g[f"{tag}_tokens"]) < 5e-3
+    lat = m(x)
+    assert rel(lat, g[f"{tag}_latent"]) < 2e-2
+    assert rel(m(x, mean_pool=True), g[f"{tag}_latent_meanpool"]) < 2e-2
+    enc = m(x, return_all=True)
+    assert rel(enc, g[f"{tag}_encoded"]) < 2e-2
+    m.zero_grad()
+    w = torch.linspace(-1, 1, lat.numel(), device=dev).reshape(lat.shape)
+    (m(x) * w).sum().backward()
+    named = dict(m.named_parameters())
+    for k in [k for k in g if k.startswith(f"{tag}_grad.")]:
+        n = k[len(f"{tag}_grad."):]
+        assert rel(named[n].grad, g[k]) < 5e-2, n
+
+
+def test_vit_masking_golden(dev, golden):
+    g = golden("vit_micro")
+    m = micro_vit(dev)
+    load_prefixed(m, g, "sd.", dev)
+    x = T(g["mask_x"], dev)
+    lat = m(x, mask_ratio=T(g["mask_mask"], dev))
+    assert rel(lat, g["mask_latent"]) < 2e-2
+    _, mk, ids = m.masking_indices(3, 24, T(g["mask_mask"], dev), dev)
+    assert np.array_equal(ids.cpu().numpy(), g["mask_ids_restore"]) and np.array_equal(mk.cpu().numpy(), g["mask_out_mask"])
+    lat2 = m(x, mask_ratio=0.75, noise=T(g["rand_noise"], dev))
+    assert rel(lat2, g["rand_latent"]) < 2e-2
+
+
+@pytest.mark.parametrize("tag,img", [("t96", (64, 96)), ("t208", (64, 208))])
+def test_mae_decoder_golden(dev, golden, tag, img):
+    g = golden("mae_micro")
+    m = micro_vit(dev, use_decoder=True, img_size=img)
+    load_prefixed(m, g, f"{tag}_sd.", dev)
+    x = T(g[f"{tag}_x"], dev)
+    lat, rl = m(x, mask_ratio=T(g[f"{tag}_mask"], dev), masked_recon=True)
+    assert rel(lat, g[f"{tag}_latent"]) < 2e-2
+    assert abs(float(rl) - float(g[f"{tag}_recon_loss"])) / float(g[f"{tag}_recon_loss"]) < 1e-2
+    m.zero_grad()
+    (rl + lat.sum() * 0.01).backward()
+    named = dict(m.named_parameters())
+    for k in [k for k in g if k.startswith(f"{tag}_grad.")]:
+        n = k[len(f"{tag}_grad."):]
+        assert rel(named[n].grad, g[k]) < 6e-2, n
+
+
+def test_param_counts_and_keys():
+    for size, n in [("tiny", 5390784), ("base", 85264128)]:
+        m = mae.get_mae_vit(size)
+        assert sum(p.numel() for p in m.parameters()) == n
+    keys = set(mae.get_mae_vit("tiny").state_dict())
+    for k in ["cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.q_bias",
+              "blocks.11.mlp.fc2.bias", "norm.weight"]:
+        assert k in keys
+    with pytest.raises(NotImplementedError):
+        model.ModelWrapper(hp.make_args(model_type="resnet18"))
+
+
+# ------------------------------------------------------------------------------------------------ whole step through the generic modules
+class MicroBackbone(nn.Module):
+    def __init__(self, dev):
+        super().__init__()
+        self.encoder = micro_vit(dev)
+        self.feature_dim = 128
+
+    def forward(self, x, mask_ratio=0, masked_recon=False):
+        return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon)
+
+
+@pytest.mark.parametrize("tag,stop_grad,use_pred", [("byol", True, True), ("plain", False, False)])
+def test_full_step_golden(dev, golden, tag, stop_grad, use_pred):
+    """main_bt_byol.py:79-135 driven through the drop-in classes with torch.optim.AdamW, exactly like the reference:
+    losses rel 3e-2 (bf16), first-step gradients rel 8e-2."""
+    g = golden(f"step_{tag}")
+    cfg = hp.make_args(model_type="vit_tiny", projector_hidden_dim=192, projector_out_dim=64, batch_size=8)
+    online = utils.MultiCropWrapper(MicroBackbone(dev), model.BarlowTwinsHead(cfg, 128)).to(dev)
+    load_prefixed(online, g, "online_sd.", dev)
+    predictor = model.BarlowTwinsPredictor(64, use=use_pred).to(dev)
+    if use_pred:
+        load_prefixed(predictor, g, "pred_sd.", dev)
+    target = utils.MultiCropWrapper(MicroBackbone(dev), model.BarlowTwinsHead(cfg, 128)).to(dev)
+    target.load_state_dict(online.state_dict())
+    if stop_grad:
+        for p in target.parameters():
+            p.requires_grad = False
+    crit = BarlowTwinsLoss(cfg, ncrops=2).to(dev)
+    groups = utils.get_param_groups(online)
+    if use_pred:
+        groups += utils.get_param_groups(predictor)
+    if not stop_grad:
+        groups += utils.get_param_groups(target)
+    opt = torch.optim.AdamW(groups, lr=float(g["lr"]), weight_decay=float(g["wd"]))
+    images = [T(g["view0"], dev), T(g["view1"], dev)]
+    ema = utils.EMA(0.99)
+    losses = []
+    for it in range(2):
+        o = online(images[:2], ncrops=2)
+        o = predictor(o, ncrops=1)
+        t = target(images, ncrops=2)
+        loss = crit(o, t, ngcrops_each=2)
+        losses.append(float(loss))
+        if stop_grad:
+            utils.update_moving_average(ema, target, online)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            named = dict(online.named_parameters())
+            for k in [k for k in g if k.startswith("grad0.")]:
+                assert rel(named[k[len("grad0."):]].grad, g[k]) < 8e-2, k
+        opt.step()
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-2)
+    sd = online.state_dict()
+    for k in [k for k in g if k.startswith("online_sd_after.") and "num_batches" not in k]:
+        np.testing.assert_allclose(sd[k[len("online_sd_after."):]].cpu().numpy(), g[k], rtol=2e-2, atol=4e-5, err_msg=k)
+    tsd = target.state_dict()
+    for k in [k for k in g if k.startswith("target_sd_after.") and "num_batches" not in k]:
+        np.testing.assert_allclose(tsd[k[len("target_sd_after."):]].cpu().numpy(), g[k], rtol=2e-2, atol=4e-5, err_msg=k)
+
+
+def test_misc_golden(dev, golden):
+    g = golden("misc")
+
+    class Bk(nn.Module):
+        def forward(self, x):
+            return x.mean(dim=(1, 2)).unsqueeze(1) * torch.ones(1, 3, device=x.device) + x.shape[-1]
+
+    class Hd(nn.Module):
+        def forward(self, x, ncrops):
+            return x * ncrops
+
+    mc = utils.MultiCropWrapper(Bk(), Hd())
+    xs = [T(g[f"mc_x{i}"], dev) for i in range(5)]
+    np.testing.assert_allclose(mc(xs, ncrops=5).cpu().numpy(), g["mc_out"], atol=1e-5)
+    a, b = nn.Linear(4, 3).to(dev), nn.Linear(4, 3).to(dev)
+    with torch.no_grad():
+        a.weight.copy_(T(g["ema_old_w"], dev)); b.weight.copy_(T(g["ema_new_w"], dev))
+    utils.update_moving_average(utils.EMA(0.99), a, b)
+    np.testing.assert_allclose(a.weight.detach().cpu().numpy(), g["ema_out_w"], atol=1e-6)
+    cfg = hp.make_args(model_type="vit_tiny", projector_hidden_dim=192, projector_out_dim=64)
+    online = utils.MultiCropWrapper(MicroBackbone(dev), model.BarlowTwinsHead(cfg, 128))
+    groups = utils.get_param_groups(online)
+    names = {id(p): n for n, p in online.named_parameters()}
+    assert [names[id(p)] for p in groups[0]["params"]] == g["pg_regularized"].tolist()
+    assert [names[id(p)] for p in groups[1]["params"]] == g["pg_not_regularized"].tolist()
+    assert groups[1]["weight_decay"] == 0.
+
+
+# ------------------------------------------------------------------------------------------------ augmentation modules
+@pytest.mark.parametrize("tag", ["seq96", "seq208", "seq96_local"])
+def test_audio_pair_transform_golden(dev, golden, tag):
+    """Per-sample drop-in modules, seeded like the reference run: same draws, same bank evolution; |diff| <= 2e-4."""
+    g = golden("augment")
+    clips = g[f"apt_{tag}_clips"]
+    L = int(g[f"apt_{tag}_L"])
+    seed = int(g[f"apt_{tag}_seed"])
+    torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+    args = hp.make_args(model_type="vit_tiny", crop_frames=clips.shape[-1], local_crops_number=L)
+    tfm = transforms.AudioPairTransform(args)
+    for k, c in enumerate(clips):
+        crops = tfm(T(c, dev))
+        assert len(crops) == 2 + L
+        for v in range(2):
+            assert np.abs(crops[v].cpu().numpy() - g[f"apt_{tag}_views"][k, v]).max() < 2e-4
+        for l in range(L):
+            assert np.abs(crops[2 + l].cpu().numpy() - g[f"apt_{tag}_locals"][k, l]).max() < 2e-4
+
+
+def test_batched_augment_matches_sequential_oracle(dev):
+    """BatchedPairAugment over 3 batches of 4 clips == the oracle's sequential per-clip pipeline with the same seed
+    (bank spans batches; ring slots resolved on the host)."""
+    from oracle import augment as oaug
+    B, T_ = 4, 208
+    rng = np.random.RandomState(5)
+    ba = aug.BatchedPairAugment(dev, 64, T_, T_, seed=11, n_memory=10)      # small FIFO so eviction is exercised
+    orc = oaug.PairTransformOracle(crop_frames=T_, seed=11, n_memory=10)
+    for it in range(3):
+        clips = (rng.randn(B, 64, T_) * 1.3 - 0.2).astype(np.float32)
+        ba.next_slots(B).copy_(T(clips, dev))
+        views = ba(B).cpu().numpy()
+        for b in range(B):
+            ref = orc(clips[b][None])
+            for v in range(2):
+                assert np.abs(views[v, b] - ref[v]).max() < 2e-4, (it, b, v)
+    assert [r["rrc"] for r in ba.records] == [tuple(r["rrc"]) for r in orc.records[-2 * B:]]
+
+
+def test_log_mixup_exp_and_normalize_golden(dev, golden):
+    g = golden("augment")
+    for k in range(4):
+        y = aug.log_mixup_exp(T(g["lme_xa"], dev), T(g["lme_xb"], dev), float(g[f"lme_{k}_alpha"]))
+        assert np.abs(y.cpu().numpy() - g[f"lme_{k}_out"]).max() < 1e-5
+    y = aug.NormalizeBatch()(T(g["nb_x"], dev))
+    assert np.abs(y.cpu().numpy() - g["nb_y"]).max() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ the trainer (bench path) vs the oracle
+def test_trainer_step_vs_oracle(dev):
+    """Whole hot path: waveform -> log-mel -> views -> ViT-T + projector -> BT loss -> backward -> fused AdamW, against
+    the CPU oracle on identical inputs / draws.  Loss rel 5e-2 (bf16 through 12 blocks; BT loss amplifies)."""
+    from ssl_audio_amd import selfcheck
+    loss, ref = selfcheck.smoke(n_clips=8, seconds=1.0, verbose=False)
+    assert abs(loss - ref) / abs(ref) < 5e-2
