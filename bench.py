@@ -37,8 +37,8 @@ def cpu_baseline(workload, budget_clips=4, steps=2):
     import numpy as np
     model_type, seconds, _, _ = WORKLOADS[workload]
     size = model_type.split("_")[-1]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)                  # the cores this process may actually run on (cgroup / affinity aware)
     n_samples = int(seconds * 16000)
     T = n_samples // 160 + 1
     heads = {"tiny": 3, "small": 6, "base": 12}[size]
@@ -64,13 +64,17 @@ def cpu_baseline(workload, budget_clips=4, steps=2):
         views = [torch.from_numpy(np.stack(x)).float() for x in v]
         return ostep.bt_step(sd, views, heads, (4, 6), opt)[0]
 
-    one_step()                                    # warm-up
+    t0 = time.time()
+    one_step()                                    # warm-up (also sizes the sample: stay within ~30 s of CPU work)
+    warm = time.time() - t0
+    print(f"[bench] cpu baseline warm-up step: {warm:.1f}s on {cores} cores", file=sys.stderr, flush=True)
+    steps = max(1, min(steps, int(20.0 / max(warm, 1e-3))))
     t0 = time.time()
     for _ in range(steps):
         one_step()
     dt = time.time() - t0
     return {"value": budget_clips * steps / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{budget_clips} clips x {steps} steps after 1 warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
+            "sample": f"{budget_clips} clips x {steps} step(s) after 1 warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
                       f"{torch.get_num_threads()} threads (oracle/: frontend + augment + fwd/bwd + AdamW)"}
 
 
@@ -88,6 +92,7 @@ def main():
     from ssl_audio_amd.selfcheck import synthetic_waveforms
     from ssl_audio_amd.train import BarlowTwinsTrainer
 
+    t_start = time.perf_counter()
     rank, local, world = sdist.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -115,13 +120,20 @@ def main():
             w += a * torch.sin(2 * torch.pi * f * t)
         pool.append(w.contiguous())
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    note(f"model + {2 * B} synthetic clips resident; warm-up x{args.warmup}")
     for i in range(args.warmup):
         trainer.step(pool[i % 2])
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done (loss {float(trainer.last_loss):.4f})")
     barrier()
     ops.GEMM_PROFILE = []                                          # HIP events around every GEMM launch of the timed region
     t0 = time.perf_counter()
@@ -130,6 +142,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    note(f"timed region done: {args.steps} steps in {dt:.3f}s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -164,7 +177,9 @@ def main():
                          "whole_step_tflops": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2)},
         }
         if not args.no_cpu_baseline:
+            note("timing the CPU baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline(args.workload)
+            note("CPU baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   const int px = (canvas_w - T_in) / 2, py = (canvas_h - F_in) / 2;
 
   // source-column window of this slab (crop coordinates), align_corners=True
-  const float sx = T_out > 1 ? (float)(cw - 1) / (float)(T_out - 1) : 0.f;
-  const float sy = F_out > 1 ? (float)(ch - 1) / (float)(F_out - 1) : 0.f;
+  const float sx = T_out > 1 ? __fdiv_rn((float)(cw - 1), (float)(T_out - 1)) : 0.f;   // IEEE division, as the CPU reference
+  const float sy = F_out > 1 ? __fdiv_rn((float)(ch - 1), (float)(F_out - 1)) : 0.f;
   const int xlo = max(0, (int)floorf(__fmul_rn(sx, (float)t0)) - 1);
   const int xhi = min(cw - 1, (int)floorf(__fmul_rn(sx, (float)(t0 + nt - 1))) + 2);
   const int wt = xhi - xlo + 1;  // host guarantees wt <= LDS_W via TT
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
     const int fy = idx / nt, tx = idx - fy * nt;
     const int t = t0 + tx;
     // rounded products (no FMA contraction into the fraction): PyTorch's CPU kernel rounds scale*index to fp32 first
-    const float rx = __fmul_rn(sx, (float)t), ry = __fmul_rn(sy, (float)fy);
+    float rx = sx * (float)t, ry = sy * (float)fy;
+    asm volatile("" : "+v"(rx), "+v"(ry));   // keep the ROUNDED products: hipcc would otherwise contract x*y - floor into an fma
     const float fx = floorf(rx), fyf = floorf(ry);
     float wx[4], wy[4];
     cubic_w(rx - fx, wx);

@@ -125,8 +125,8 @@ class MlpBnReluFn(torch.autograd.Function):
         dz16 = ops.cast_bf16(dz.contiguous())
         dw1b, dw1 = grad_target(w1)
         _wgrad(dz16, a, dw1b)
-        da = torch.empty(B, Hd, dtype=BF16, device=dev)
-        ops.gemm(dz16, BF16_WEIGHTS.get(w1), b_kmajor=False, out_bf16=da)
+        da = torch.empty(B, Hd, device=dev)      # fp32: BN backward subtracts batch means, keep its input unrounded
+        ops.gemm(dz16, BF16_WEIGHTS.get(w1), b_kmajor=False, out_f32=da)
         s = torch.empty(2, Hd, device=dev)
         ops.bn_bwd_stats(da, h, mean, rstd, gamma, beta, True, s[0], s[1])
         dgb, dgamma = grad_target(gamma)                    # local contributions (summed over ranks with the other grads)
