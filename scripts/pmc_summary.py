@@ -1,0 +1,12 @@
+import csv, glob, sys, collections
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "gemm" not in k: continue
+        agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")

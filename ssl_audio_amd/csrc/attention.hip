@@ -18,6 +18,8 @@ namespace {
 constexpr int HD = 64;          // head dim
 constexpr int NMAX = 256;       // max tokens per sequence
 constexpr int IMG = NMAX * HD * 2;  // bytes of one [256][64] bf16 LDS image
+constexpr int NW_FWD = 4;           // waves per workgroup, forward
+constexpr int NW_BWD = 8;           // backward: 133 KiB of LDS allows one workgroup per CU, so give it 8 waves to hide latency
 
 // ---- LDS image: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7)
 __device__ __forceinline__ int img_off(int row, int col) {  // col in elements, multiple of 4
@@ -25,9 +27,9 @@ __device__ __forceinline__ int img_off(int row, int col) {  // col in elements, 
 }
 
 // stage rows [0, nrows) of a strided global matrix (row stride ld elements, starting column col0) into an image
-__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* img, int ld, int col0, int nrows, int wave, int lane) {
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, char* img, int ld, int col0, int nrows, int wave, int lane, int nwaves) {
   const int ninstr = (nrows + 7) >> 3;
-  for (int q = wave; q < ninstr; q += 4) {
+  for (int q = wave; q < ninstr; q += nwaves) {
     const int row = q * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ (row & 7);
     const uint32_t voff = ((uint32_t)row * (uint32_t)ld + (uint32_t)(col0 + chunk * 8)) * 2u;
@@ -78,13 +80,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
 
   const int nkt = (N + 15) >> 4;           // 16-key tiles
   const int nks = (N + 31) >> 5;           // 32-key steps for P.V
-  stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane);
-  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane);
+  stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane, NW_FWD);
+  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane, NW_FWD);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int g = lane >> 4, c = lane & 15;
-  for (int qt = wave; qt < nkt; qt += 4) {
+  for (int qt = wave; qt < nkt; qt += NW_FWD) {
     // Q fragments for this lane's query (Y operand: k = d)
     const int query = qt * 16 + c;
     bf16x8 qf[2];
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // =====================================================================================================
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+__global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, int ldo,
                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,15 +176,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   const int nkt = (N + 15) >> 4;
   const int nks = (N + 31) >> 5;
   const int nrows = nks * 32;
-  stage_rows(rs, Qimg, ld, h * HD, nrows, wave, lane);
-  stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane);
-  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane);
-  stage_rows(rd, Dimg, ldo, h * HD, nrows, wave, lane);
+  stage_rows(rs, Qimg, ld, h * HD, nrows, wave, lane, NW_BWD);
+  stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
+  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
+  stage_rows(rd, Dimg, ldo, h * HD, nrows, wave, lane, NW_BWD);
   // delta[q] = sum_d dO[q][d] * O[q][d]  (straight from global, one query row per thread), lse -> LDS
   {
     const int q = threadIdx.x;
     float dl = 0.f, ls = 0.f;
-    if (q < N) {
+    if (q < N && q < NMAX) {
       const bf16x8* po = reinterpret_cast<const bf16x8*>(o + (row_base + q) * ldo + h * HD);
       const bf16x8* pd = reinterpret_cast<const bf16x8*>(dout + (row_base + q) * ldo + h * HD);
 #pragma unroll
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
       }
       ls = lse[((int64_t)s * H + h) * N + q];
     }
-    del_s[q] = dl;
-    lse_s[q] = ls;
+    if (q < NMAX) {
+      del_s[q] = dl;
+      lse_s[q] = ls;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   const int g = lane >> 4, c = lane & 15;
 
   // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
-  for (int qt = wave; qt < nkt; qt += 4) {
+  for (int qt = wave; qt < nkt; qt += NW_BWD) {
     const int query = qt * 16 + c;
     const bf16x8 qf0 = row_frag(Qimg, qt * 16, 0, lane), qf1 = row_frag(Qimg, qt * 16, 1, lane);
     const bf16x8 df0 = row_frag(Dimg, qt * 16, 0, lane), df1 = row_frag(Dimg, qt * 16, 1, lane);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   }
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
     const bf16x8 kf0 = row_frag(Kimg, kt * 16, 0, lane), kf1 = row_frag(Kimg, kt * 16, 1, lane);
@@ -330,7 +334,7 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
     configured = true;
   }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
                      (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   SA_LAUNCH_CHECK("sa_attention_bwd");
   return 0;

@@ -9,6 +9,7 @@
 // and wgrad (TN) are the same kernel and no transposed copy of a weight or activation is ever made.
 // LDS destination of an LDS-DMA is lane-linear, so swizzles are applied to the per-lane SOURCE address
 // and again on the fragment read (cdna_hip_programming.md rule 21).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
 
@@ -41,13 +42,14 @@ __device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >
 
 // ---- HBM -> LDS staging of one operand tile ---------------------------------------------------------
 // k-major operand: tile = 128 rows x 64 k (128 B rows).  16 wave-instructions of 1 KiB (8 rows each).
-template <bool KMAJOR>
+template <bool KMAJOR, int NWAVES = 4>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
                                            int wave, int lane) {
+  constexpr int PER_WAVE = 16 / NWAVES;
   if constexpr (KMAJOR) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = wave * 4 + i;
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave * PER_WAVE + i;
       const int row = q * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ (row & 7);
       const uint32_t voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
@@ -56,8 +58,8 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   } else {
     // k-strided operand: tile = 64 k-rows x 128 cols (256 B rows).  16 wave-instructions (4 k-rows each).
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = wave * 4 + i;
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave * PER_WAVE + i;
       const int krow = q * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ ks_swz(krow);
       const uint32_t voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
@@ -88,6 +90,161 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int sub0, int 
   }
 }
 
+// ---- epilogue for one accumulator fragment: lane owns row m and columns n..n+3 (swapped MFMA operand order)
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4& a, int m, int n, int64_t orow, int64_t rrow) {
+  if (n >= p.N) return;
+  if (n + 3 >= p.N) {
+    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+      float x = a[r] * p.alpha;
+      if (p.bias) x += p.bias[n + r];
+      if (p.act == 1) {
+        if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
+        x = gelu_f(x);
+      } else if (p.act == 2) {
+        x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
+      }
+      if (p.residual) x += p.residual[rrow * p.ldr + n + r];
+      if (p.out_f32) {
+        float* o = p.out_f32 + orow * p.ldo_f32 + n + r;
+        *o = p.accumulate ? *o + x : x;
+      }
+      if (p.out_bf16) p.out_bf16[orow * p.ldo_bf16 + n + r] = f2bf(x);
+    }
+    return;
+  }
+  float v[4] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha};
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.act == 1) {
+    if (p.aux_out) {
+      bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+  } else if (p.act == 2) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+  }
+  if (p.residual) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.out_f32) {
+    float* o = p.out_f32 + orow * p.ldo_f32 + n;
+    if (p.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+    }
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (p.out_bf16) {
+    bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(p.out_bf16 + orow * p.ldo_bf16 + n) = h;
+  }
+}
+
+// ---- wave-private staged epilogue for a 64 x 64 wave tile (acc[4][4], swapped operand order: lane = row c, cols 4g..)
+// A row-per-lane bf16 epilogue is 16 x 8-byte stores per lane, each instruction touching 16 rows x 32 B: the store
+// tail is ISSUE-bound (cdna_hip_programming.md T21).  Staging the tile through 9 KiB of this wave's LDS turns it
+// into 8 x 16-byte stores per lane that write whole 128-byte row segments.  fp32 outputs already store 16 B per lane.
+constexpr int EPI_STRIDE = 144;                 // bytes per staged row: 64 bf16 + 16 B pad (16-byte aligned rows)
+constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
+
+__device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32x4 (&v)[4][4], char* wlds, bf16_t* dst, int64_t ld,
+                                                  int m_base, int n_base, bool remap, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 h = {f2bf(v[i][j][0]), f2bf(v[i][j][1]), f2bf(v[i][j][2]), f2bf(v[i][j][3])};
+      *reinterpret_cast<bf16x4*>(wlds + (i * 16 + c) * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
+    }
+  const int ch = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int m = m_base + r;
+    const uint4 val = *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
+    if (m < p.M) {
+      const int64_t orow = (remap && p.row_group > 0) ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+      *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const bool fast = (n_base + 64 <= p.N) &&
+                    (!p.out_bf16 || ((p.ldo_bf16 & 7) == 0 && ((uintptr_t)p.out_bf16 & 15) == 0)) &&
+                    (!p.aux_out || ((p.ldaux & 7) == 0 && ((uintptr_t)p.aux_out & 15) == 0));
+  if (!fast) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_base + i * 16 + c;
+      if (m >= p.M) continue;
+      const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+      const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) epilogue_store(p, acc[i][j], m, n_base + j * 16 + 4 * g, orow, rrow);
+    }
+    return;
+  }
+  // v = alpha * acc + bias
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i][j][0] = acc[i][j][0] * p.alpha + b.x; acc[i][j][1] = acc[i][j][1] * p.alpha + b.y;
+      acc[i][j][2] = acc[i][j][2] * p.alpha + b.z; acc[i][j][3] = acc[i][j][3] * p.alpha + b.w;
+    }
+  }
+  if (p.act == 1) {
+    if (p.aux_out) staged_store_bf16(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_f(acc[i][j][r]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_base + i * 16 + c;
+    if (m >= p.M) continue;
+    const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+    const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n_base + j * 16 + 4 * g;
+      if (p.act == 2) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= dgelu_f(bf2f(h[r]));
+      }
+      if (p.residual) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
+        acc[i][j][0] += rv.x; acc[i][j][1] += rv.y; acc[i][j][2] += rv.z; acc[i][j][3] += rv.w;
+      }
+      if (p.out_f32) {
+        float* o = p.out_f32 + orow * p.ldo_f32 + n;
+        if (p.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(o);
+          acc[i][j][0] += old.x; acc[i][j][1] += old.y; acc[i][j][2] += old.z; acc[i][j][3] += old.w;
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  }
+  if (p.out_bf16) staged_store_bf16(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
@@ -102,9 +259,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ks_id = lid % p.split_k;
-  const int tile = lid / p.split_k;
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  // split-K slice is the SLOWEST index (blocks that run together reduce over the same rows and share them in L2);
+  // tiles are walked in groups of GM row-panels with m fastest, so the ~64 blocks resident on one XCD cover about
+  // 8 x 8 tiles: 8 A panels + 8 B panels stay in its 4 MiB L2 instead of streaming every B panel per tile.
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int ks_id = lid / ntiles;
+  const int tile = lid - ks_id * ntiles;
+  constexpr int GM = 8;
+  const int group_sz = GM * p.tiles_n;
+  const int grp = tile / group_sz, within = tile - grp * group_sz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tm = grp * GM + within % gm, tn = within / gm;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int ksteps = (p.K + BK - 1) / BK;
@@ -175,73 +340,310 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
         }
       }
   } else {
-    // lane owns one row m and 4 consecutive columns n..n+3
+    wave_epilogue_64x64(p, acc, m0 + wr * 64, n0 + wc * 64, smem + wave * EPI_BYTES, lane);
+  }
+}
+
+// =====================================================================================================
+// 256 x 256 x 64 tile, 512 threads = 8 waves (2 x 4), each wave 128 x 64 (8 x 4 MFMA tiles, 128 accumulator VGPRs),
+// one workgroup per CU (2 x 64 KiB LDS buffers).  Why: a CU pulls L2-resident operands at only ~30 B/clk, so the
+// 128^2 kernel (32 KiB of operands per 2.1 MFLOP) is bound by that path long before the MFMA pipe; 256^2 halves
+// the bytes per FLOP.  Each operand tile is two of the 128-wide half-tiles above, so staging and fragment reads are
+// the same code.  Per K-tile the wave walks four C-quadrants (A-half0 x B-half0, A0 x B1, A1 x B1, A1 x B0) so only
+// 12 fragment registers sets are live; the next K-tile's 4 half-tiles are requested at the top of the iteration and
+// awaited at its end (one barrier per K-tile).
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A half0 | A half1 | B half0 | B half1]
+  constexpr int BUF = 4 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;      // wave rows wr*128.., cols wc*64..
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  constexpr int GM = 4;                          // 32 blocks per XCD ~ 4 x 8 tiles in flight
+  const int group_sz = GM * p.tiles_n;
+  const int grp = lid / group_sz, within = lid - grp * group_sz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tm = grp * GM + within % gm, tn = within / gm;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int ksteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wr * 64 + i * 16 + c;
-      if (m >= p.M) continue;
-      const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-      const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + 4 * g;
-        if (n >= p.N) continue;
-        float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
-        const bool full = (n + 3 < p.N);
-        if (full) {
-          if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          }
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage_all = [&](char* buf, int k0) {
+    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
+    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+  };
+
+  stage_all(smem, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    if (kt + 1 < ksteps) stage_all(smem + (cur ^ 1) * BUF, (kt + 1) * BK);
+    const char* ta = smem + cur * BUF + wr * TILE_BYTES;                 // this wave's A half-tile (128 rows)
+    const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;    // this wave's B half-tile
+    const int bcol = (wc & 1) * 64;
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // quadrant (0,0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+    // quadrant (0,1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+    // quadrant (1,1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+    // quadrant (1,0)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue (lane: one row m, 4 consecutive n)
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + c;
+    if (m >= p.M) continue;
+    const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
+    const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + 4 * g;
+      if (n + 3 >= p.N) {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          float x = acc[i][j][r] * p.alpha;
+          if (p.bias) x += p.bias[n + r];
           if (p.act == 1) {
-            if (p.aux_out) {
-              bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-              *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
+            x = gelu_f(x);
           } else if (p.act == 2) {
-            const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+            x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
           }
-          if (p.residual) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          }
+          if (p.residual) x += p.residual[rrow * p.ldr + n + r];
           if (p.out_f32) {
-            float* o = p.out_f32 + orow * p.ldo_f32 + n;
-            if (p.accumulate) {
-              const float4 old = *reinterpret_cast<const float4*>(o);
-              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-            }
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            float* o = p.out_f32 + orow * p.ldo_f32 + n + r;
+            *o = p.accumulate ? *o + x : x;
           }
-          if (p.out_bf16) {
-            bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            *reinterpret_cast<bf16x4*>(p.out_bf16 + orow * p.ldo_bf16 + n) = h;
-          }
-        } else {
-          for (int r = 0; r < 4 && n + r < p.N; ++r) {
-            float x = v[r];
-            if (p.bias) x += p.bias[n + r];
-            if (p.act == 1) {
-              if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
-              x = gelu_f(x);
-            } else if (p.act == 2) {
-              x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
-            }
-            if (p.residual) x += p.residual[rrow * p.ldr + n + r];
-            if (p.out_f32) {
-              float* o = p.out_f32 + orow * p.ldo_f32 + n + r;
-              *o = p.accumulate ? *o + x : x;
-            }
-            if (p.out_bf16) p.out_bf16[orow * p.ldo_bf16 + n + r] = f2bf(x);
-          }
+          if (p.out_bf16) p.out_bf16[orow * p.ldo_bf16 + n + r] = f2bf(x);
         }
+        continue;
+      }
+      float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (p.act == 1) {
+        if (p.aux_out) {
+          bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.act == 2) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+      }
+      if (p.residual) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+      }
+      if (p.out_f32) {
+        float* o = p.out_f32 + orow * p.ldo_f32 + n;
+        if (p.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(o);
+          v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (p.out_bf16) {
+        bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(p.out_bf16 + orow * p.ldo_bf16 + n) = h;
       }
     }
   }
+}
+
+template <bool A_KM, bool B_KM>
+int launch256(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              8 * TILE_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM>), dim3(p.tiles_m * p.tiles_n), dim3(512), 8 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256)");
+  return 0;
+}
+
+// =====================================================================================================
+// 256 x 128 x 64 tile, THREE LDS stages (3 x 48 KiB), 512 threads = 8 waves (4 x 2, each 64 x 64).
+// The K-tile two steps ahead is requested at the top of every iteration and only the one needed NEXT is awaited
+// (`s_waitcnt vmcnt(6)`: this wave's 6 newest LDS-DMA requests stay in flight across the raw s_barrier), so operand
+// delivery from L2 has two full iterations of MFMA work to hide behind instead of being a burst-then-wait.
+// Requests past the last K-tile are sent out of range (zero fill, no memory traffic) so the count stays exact.
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
+                                            int wave, int lane, bool valid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = wave * 2 + i;
+    uint32_t voff;
+    if constexpr (KMAJOR) {
+      const int row = q * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (row & 7);
+      voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
+    } else {
+      const int krow = q * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ ks_swz(krow);
+      voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
+    }
+    voff = valid ? voff : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A half0 | A half1 | B]
+  constexpr int STAGE = 3 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;      // wave rows wr*64.., cols wc*64..
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  const int grp = lid / group_sz, within = lid - grp * group_sz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tm = grp * GM + within % gm, tn = within / gm;
+  const int m0 = tm * 256, n0 = tn * 128;
+
+  const int ksteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int slot, int kt) {
+    char* buf = smem + slot * STAGE;
+    const bool valid = kt < ksteps;
+    stage_tile8<A_KM>(ra, buf, p.lda, m0, kt * BK, wave, lane, valid);
+    stage_tile8<A_KM>(ra, buf + TILE_BYTES, p.lda, m0 + 128, kt * BK, wave, lane, valid);
+    stage_tile8<B_KM>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, kt * BK, wave, lane, valid);
+  };
+
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int slot = 0;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    int nslot = slot + 2;
+    if (nslot >= 3) nslot -= 3;
+    stage(nslot, kt + 2);
+    const char* ta = smem + slot * STAGE + (wr >> 1) * TILE_BYTES;
+    const char* tb = smem + slot * STAGE + 2 * TILE_BYTES;
+    const int arow = (wr & 1) * 64, bcol = wc * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KM>(ta, arow + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    // own LDS reads retired (the slot just read is re-staged right after the barrier) + next K-tile's DMA landed
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    slot = slot + 1 == 3 ? 0 : slot + 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the out-of-range tail requests still zero-fill LDS: let them land
+  __builtin_amdgcn_s_barrier();
+  wave_epilogue_64x64(p, acc, m0 + wr * 64, n0 + wc * 64, smem + wave * EPI_BYTES, lane);
+}
+
+template <bool A_KM, bool B_KM>
+int launch_p3(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 127) / 128;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p3_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              9 * TILE_BYTES);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_p3_kernel<A_KM, B_KM>), dim3(p.tiles_m * p.tiles_n), dim3(512), 9 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(p3)");
+  return 0;
 }
 
 template <bool A_KM, bool B_KM, bool SWAP>
@@ -288,6 +690,34 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int
   if (ph == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// vectorised column sums: a block covers 256 columns (32 lanes x 8 bf16 = 512 contiguous bytes per row) x 8 row lanes,
+// so every load is a full-line 16-byte access; partial sums meet in LDS and leave as one atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out,
+                                                              int rows_per_block) {
+  __shared__ float red[8][256 + 8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + col);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += bf2f(v[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[ty][tx * 8 + k] = a[k];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    atomicAdd(out + c, s);
+  }
+}
+
 }  // namespace
 
 extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
@@ -331,6 +761,25 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
 
+  // large dense problems go to the 256 x 256 kernel (half the operand bytes per FLOP through the CU's L2 path)
+  static const char* force = getenv("SA_GEMM_TILE");
+  const bool big = a->split_k == 1 && a->M >= 1024 && a->N >= 256 && (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 128;
+  const char mode = force ? force[0] : '1';   // measured: the 128^2 kernel (2 workgroups per CU overlap each other's epilogue) wins at K = 768
+  if (mode == '3' && a->split_k == 1) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch_p3<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch_p3<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch_p3<false, true>(p, stream);
+    return launch_p3<false, false>(p, stream);
+  }
+  if (mode == '2' && a->split_k == 1) {
+    // the 256-wide tile reads up to 256 rows past the last valid one: keep the descriptor range check honest
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch256<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256<false, true>(p, stream);
+    return launch256<false, false>(p, stream);
+  }
   const bool swap = a->split_k == 1;
   const int sel = (a->a_kmajor ? 4 : 0) | (a->b_kmajor ? 2 : 0) | (swap ? 1 : 0);
   switch (sel) {
@@ -363,6 +812,17 @@ extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, f
       sa_set_error("sa_colsum_bf16: memset failed");
       return 2;
     }
+  }
+  if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0) {
+    const int gx = (N + 255) / 256;
+    int gy = (2048 + gx - 1) / gx;
+    const int max_gy = (M + 63) / 64;
+    if (gy > max_gy) gy = max_gy;
+    const int rows_per_block = (((M + gy - 1) / gy) + 7) / 8 * 8;
+    gy = (M + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block);
+    SA_LAUNCH_CHECK("sa_colsum_bf16");
+    return 0;
   }
   const int gx = (N + 63) / 64;
   int gy = (2048 + gx - 1) / gx;

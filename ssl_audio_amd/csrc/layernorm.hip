@@ -6,9 +6,10 @@
 
 namespace {
 
-constexpr int MAXV = 8;  // float4 per lane -> D <= 64 * 4 * 8 = 2048
+constexpr int MAXV_LIMIT = 8;  // float4 per lane -> D <= 64 * 4 * 8 = 2048 (kernels are instantiated for 1, 2, 3, 4, 8)
 
 // y = (x - mean) * rstd * gamma + beta ; writes bf16 and/or fp32, saves mean / rstd per row
+template <int MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y_bf16,
                                                      float* __restrict__ y_f32, int64_t ldy, float* __restrict__ mean_out,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy
 // dy arrives as bf16 (from a dgrad GEMM) or fp32 (from the loss side).  Each lane owns fixed columns, so its
 // dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + atomics at the end.
-template <typename DY>
+template <typename DY, int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
@@ -170,10 +171,13 @@ inline int ln_grid(int M) {
 extern "C" int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                                 int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, float eps, void* stream) {
   SA_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "sa_layernorm_fwd: null pointer");
-  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "sa_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV);
+  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV_LIMIT, "sa_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV_LIMIT);
   SA_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "sa_layernorm_fwd: leading dims must be multiples of 4");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16_t*)y_bf16, y_f32, ldy,
-                     mean, rstd, M, D, eps);
+  const int nv = (D / 4 + 63) / 64;
+#define SA_LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, \
+                                        (bf16_t*)y_bf16, y_f32, ldy, mean, rstd, M, D, eps)
+  if (nv <= 1) SA_LN_FWD(1); else if (nv == 2) SA_LN_FWD(2); else if (nv == 3) SA_LN_FWD(3); else if (nv == 4) SA_LN_FWD(4); else SA_LN_FWD(8);
+#undef SA_LN_FWD
   SA_LAUNCH_CHECK("sa_layernorm_fwd");
   return 0;
 }
@@ -182,17 +186,19 @@ extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy
                                 const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
                                 int64_t lddx, float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
   SA_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "sa_layernorm_bwd: null pointer");
-  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV, "sa_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV);
+  SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV_LIMIT, "sa_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV_LIMIT);
   SA_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "sa_layernorm_bwd: leading dims must be multiples of 4");
   // fewer, fatter blocks than forward: every block ends with 2*D atomics
   int grid = (M + 3) / 4;
   if (grid > 1024) grid = 1024;
-  if (dy_is_bf16)
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, x, ldx, gamma, mean,
-                       rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, gamma, mean,
-                       rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D);
+  const int nv = (D / 4 + 63) / 64;
+#define SA_LN_BWD(T, V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy, x, ldx, \
+                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D)
+#define SA_LN_BWD_V(T) do { if (nv <= 1) SA_LN_BWD(T, 1); else if (nv == 2) SA_LN_BWD(T, 2); else if (nv == 3) SA_LN_BWD(T, 3); \
+                            else if (nv == 4) SA_LN_BWD(T, 4); else SA_LN_BWD(T, 8); } while (0)
+  if (dy_is_bf16) SA_LN_BWD_V(bf16_t); else SA_LN_BWD_V(float);
+#undef SA_LN_BWD_V
+#undef SA_LN_BWD
   SA_LAUNCH_CHECK("sa_layernorm_bwd");
   return 0;
 }

@@ -13,6 +13,8 @@ C-ABI launches per transformer block with fused epilogues and a hand-planned set
 Residual stream fp32, GEMM operands / attention bf16, accumulation fp32.  `torch` only provides device
 memory here.  The autograd.Function at the bottom exposes the schedule to nn.Module callers.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -34,19 +36,20 @@ class _Bf16Cache:
 
     def pin(self, p, w16):
         """`w16` (a view of train.FlatState's bf16 buffer) is kept current by the optimiser kernel: always use it."""
-        self._pinned[id(p)] = (w16, p.data_ptr())
+        self._pinned[id(p)] = (w16, p.data_ptr(), weakref.ref(p))
 
     def get(self, p):
+        # id() values are recycled once a parameter dies, so every entry carries a weak reference to ITS parameter
         key = id(p)
         pinned = self._pinned.get(key)
-        if pinned is not None and pinned[1] == p.data_ptr():
+        if pinned is not None and pinned[2]() is p and pinned[1] == p.data_ptr():
             return pinned[0]
         ent = self._c.get(key)
         ver = (p._version, self._manual.get(key, 0))
-        if ent is None or ent[0] != ver or ent[1].device != p.device or ent[2] != p.data_ptr():
+        if ent is None or ent[3]() is not p or ent[0] != ver or ent[1].device != p.device or ent[2] != p.data_ptr():
             w = p.detach()
             w2 = w.reshape(w.shape[0], -1) if w.dim() > 1 else w
-            ent = (ver, ops.cast_bf16(w2.contiguous()), p.data_ptr())
+            ent = (ver, ops.cast_bf16(w2.contiguous()), p.data_ptr(), weakref.ref(p))
             self._c[key] = ent
         return ent[1]
 
@@ -64,9 +67,9 @@ BLOCK_DONE_HOOK = None
 
 def grad_target(p):
     """(buffer to accumulate d/dp into, value to return to autograd)."""
-    t = GRAD_SINK.get(id(p))
-    if t is not None:
-        return t, None
+    ent = GRAD_SINK.get(id(p))
+    if ent is not None and ent[0]() is p:
+        return ent[1], None
     t = torch.zeros_like(p)
     return t, t
 

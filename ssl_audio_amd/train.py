@@ -12,6 +12,7 @@ Parameters, gradients and Adam moments live in flat buffers (`FlatState`); the n
 into them, so state_dict()/load_state_dict() keep the reference's key names.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -61,7 +62,7 @@ class FlatState:
             p.data = self.params[off:off + n].view(p.shape)
             self.offsets[name] = (off, n)
             if off < self.n_train:
-                engine.GRAD_SINK[id(p)] = self.grads[off:off + n].view(p.shape)
+                engine.GRAD_SINK[id(p)] = (weakref.ref(p), self.grads[off:off + n].view(p.shape))
             off += pad8(n)
         ops.cast_bf16(self.params, self.params_bf16)
         self.bind_bf16()
@@ -113,9 +114,10 @@ class GradSync:
             return
         lo, hi = None, None
         for p in params:
-            g = engine.GRAD_SINK.get(id(p))
-            if g is None:
+            ent = engine.GRAD_SINK.get(id(p))
+            if ent is None or ent[0]() is not p:
                 continue
+            g = ent[1]
             a = (g.data_ptr() - self.flat.grads.data_ptr()) // 4
             lo = a if lo is None else min(lo, a)
             hi = a + g.numel() if hi is None else max(hi, a + g.numel())
