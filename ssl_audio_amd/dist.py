@@ -50,9 +50,10 @@ def all_gather_rows(t):
     W = get_world_size()
     if W == 1:
         return t.unsqueeze(0)
-    out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
-    return out
+    flat = t.contiguous().view(-1)
+    out = torch.empty(W * flat.numel(), dtype=t.dtype, device=t.device)      # 1-D in / 1-D out: accepted by RCCL and gloo alike
+    dist.all_gather_into_tensor(out, flat)
+    return out.view((W,) + tuple(t.shape))
 
 
 def all_reduce_sum_(t):

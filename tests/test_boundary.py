@@ -1,0 +1,160 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol the public header
+declares, the product package never touches the oracle, and the host-side mirrors keep the reference's names."""
+import ast
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ssl_audio_amd")
+
+
+def test_library_exports_every_header_symbol():
+    from ssl_audio_amd import _lib
+    syms = _lib.header_symbols()
+    assert len(syms) >= 25 and "sa_gemm_bf16" in syms and "sa_attention_bwd" in syms
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(h, s)]
+    assert not missing, missing
+    h.sa_abi_version.restype = ctypes.c_int
+    assert h.sa_abi_version() == 1
+    # every declared function has ctypes argument types (a missing entry would silently pass ints as 32-bit)
+    assert [s for s in syms if s not in _lib._SIGNATURES and s != "sa_last_error"] == []
+
+
+def test_header_has_no_torch_types_and_cites_reference():
+    text = open(os.path.join(ROOT, "include", "ssl_audio_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # declarations only (comments may cite torch semantics)
+    assert "at::" not in code and "torch" not in code.lower() and "Tensor" not in code
+    for cite in ["models/mae.py:", "utils/loss.py:", "augmentations.py:", "datasets.py:", "model.py:", "utils/utils.py:"]:
+        assert cite in text, cite
+
+
+def test_gemm_struct_layout_matches_header():
+    """Field order of the ctypes mirror == field order in the C struct."""
+    from ssl_audio_amd._lib import SaGemmArgs
+    text = open(os.path.join(ROOT, "include", "ssl_audio_hip.h")).read()
+    body = text[text.index("typedef struct SaGemmArgs {"):text.index("} SaGemmArgs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        parts = [p.strip().split()[-1].lstrip("*") for p in decl.split(",") if p.strip()]
+        names.extend(parts)
+    assert names == [f[0] for f in SaGemmArgs._fields_]
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only selfcheck.py (smoke's checker) may mention the oracle, and only inside functions (lazy import)."""
+    for dirpath, _, files in os.walk(PKG):
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, fn)).read()
+            tree = ast.parse(src)
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or ""]
+                for m in mods:
+                    if m == "oracle" or m.startswith("oracle."):
+                        assert fn == "selfcheck.py", f"{fn} imports the oracle"
+            if fn == "selfcheck.py":
+                top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+                assert all(not ((getattr(n, "module", "") or "").startswith("oracle")) for n in top)
+    for fn in os.listdir(os.path.join(PKG, "csrc")):
+        if fn.endswith((".hip", ".h")):
+            src = open(os.path.join(PKG, "csrc", fn)).read()
+            assert "oracle/" not in src and not re.search(r"#include\s*[\"<][^\">]*oracle", src), fn
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from ssl_audio_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libssl_audio_hip.so")
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    """There is no CPU fallback: a CPU tensor is an error, not a slow path."""
+    import torch
+    from ssl_audio_amd import ops
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16), out_f32=torch.zeros(64, 64))
+
+
+def test_reference_names_and_state_dict_keys():
+    import torch
+    from ssl_audio_amd import augmentations, hyperparameters as hp, loss, mae, model, transforms, utils
+    for mod, names in [(model, ["ModelWrapper", "BarlowTwinsHead", "BarlowTwinsPredictor", "ViT"]),
+                       (loss, ["BarlowTwinsLoss"]),
+                       (utils, ["MultiCropWrapper", "EMA", "update_moving_average", "off_diagonal", "init_distributed_mode",
+                                "model_setup_ddp", "get_param_groups", "is_main_process", "save_on_master"]),
+                       (transforms, ["AudioPairTransform"]),
+                       (augmentations, ["RandomResizeCrop", "RandomLinearFader", "MixupBYOLA", "NormalizeBatch", "log_mixup_exp"]),
+                       (mae, ["MaskedAutoencoderViT", "PatchEmbed", "AttentionKBiasZero", "BlockKBiasZero", "get_mae_vit"])]:
+        for n in names:
+            assert hasattr(mod, n), (mod.__name__, n)
+    cfg = hp.make_args(model_type="vit_tiny")
+    net = utils.MultiCropWrapper(model.ModelWrapper(cfg), model.BarlowTwinsHead(cfg, 192))
+    keys = set(net.state_dict())
+    for k in ["backbone.encoder.encoder.cls_token", "backbone.encoder.encoder.blocks.0.attn.qkv.weight",
+              "backbone.encoder.encoder.blocks.11.mlp.fc2.bias", "head.projector.0.weight", "head.projector.1.running_mean",
+              "head.projector.3.weight"]:
+        assert k in keys, k
+    crit = loss.BarlowTwinsLoss(cfg, ncrops=2)
+    assert set(crit.state_dict()) == {"bn.running_mean", "bn.running_var", "bn.num_batches_tracked"}
+    groups = utils.get_param_groups(net)
+    assert all(p.requires_grad for g in groups for p in g["params"]) and groups[1]["weight_decay"] == 0.
+    frozen = [n for n, p in net.named_parameters() if not p.requires_grad]
+    assert sorted(frozen) == sorted(["backbone.encoder.encoder.pos_embed", "backbone.encoder.encoder.patch_embed.proj.weight",
+                                     "backbone.encoder.encoder.patch_embed.proj.bias"])
+
+
+def test_hyperparameter_defaults_match_reference_contract():
+    from ssl_audio_amd import hyperparameters as hp
+    a = hp.get_std_parameters().parse_args(["--model_type", "vit_base", "--batch_size", "1024"])
+    hp.setup_hyperparameters(a)
+    assert (a.optimizer, a.wd) == ("AdamW", 0.06) and abs(a.lr - 1e-4 * 1024 / 128) < 1e-12
+    assert (a.lmbda, a.alpha, a.projector_out_dim, a.projector_hidden_dim) == (0.005, 1, 256, 8192)
+    assert (a.n_fft, a.win_length, a.hop_length, a.n_mels, a.f_min, a.f_max, a.crop_frames) == (1024, 1024, 160, 64, 60, 7800, 96)
+    assert a.mixup and a.RRC and a.RLF and not a.Gnoise and a.load_lms
+    b = hp.get_std_parameters().parse_args(["--no_mixup", "--load_wav", "--stop_gradient", "--predictor"])
+    assert not b.mixup and not b.load_lms and b.stop_gradient and b.predictor
+
+
+def test_host_side_pos_embed_and_sampling_match_oracle():
+    """Host logic that runs without a GPU: positional tables and the augmentation sampler's RNG call order."""
+    import random
+    from oracle import augment as oaug, vit as ovit
+    from ssl_audio_amd import augmentations as aug, pos_embed
+    np.testing.assert_allclose(pos_embed.get_2d_sincos_pos_embed(192, (4, 6)), ovit.sincos_2d(192, (4, 6)), atol=1e-12)
+    np.testing.assert_allclose(pos_embed.get_sinusoid_encoding_table(24, 384), ovit.sinusoid_table(24, 384), atol=1e-12)
+    base = pos_embed.get_2d_sincos_pos_embed(768, (4, 6))[None]
+    np.testing.assert_allclose(pos_embed.interpolate_pos_encoding(base, (4, 6), 64, 1001), ovit.interpolate_pos_embed(base, (4, 6), 64, 1001), atol=1e-12)
+    assert pos_embed.interpolate_pos_encoding(base, (4, 6), 64, 1001).shape == (1, 249, 768)
+    ba = aug.BatchedPairAugment("cpu", 64, 208, 208, seed=3, n_memory=6)
+    ba.capacity = 12                      # host-side draw only (no device store needed)
+    orc = oaug.PairTransformOracle(crop_frames=208, seed=3, n_memory=6)
+    clips = np.zeros((8, 1, 64, 208))
+    for it in range(2):
+        src, mix, par, canvas = ba.draw(4)
+        ba.clips += 4
+        for b in range(4):
+            orc(clips[4 * it + b])
+    recs = orc.records[-8:]
+    assert [r["rrc"] for r in ba.records] == [tuple(r["rrc"]) for r in recs]
+    assert [r["bank_index"] for r in ba.records] == [r["bank_index"] for r in recs]
+    np.testing.assert_allclose([r["alpha"] for r in ba.records], [r["alpha"] for r in recs])
+    # ring-slot resolution of FIFO entry k of the second batch: event e = 2*clip + view has seen e appends, the FIFO
+    # holds the last min(e, 6) of them, entry k is global append g = e - min(e, 6) + k and therefore clip g // 2
+    for r in ba.records:
+        e = 2 * r["clip"] + r["view"]
+        g = e - min(e, 6) + r["bank_index"]
+        slot = mix[r["view"] * 4 + (r["clip"] - 4)]
+        assert slot == (g // 2) % 12 and src[r["view"] * 4 + (r["clip"] - 4)] == r["clip"] % 12
