@@ -37,8 +37,9 @@ def cpu_baseline(workload, budget_clips=4, steps=2):
     import numpy as np
     model_type, seconds, _, _ = WORKLOADS[workload]
     size = model_type.split("_")[-1]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(cores)                  # the cores this process may actually run on (cgroup / affinity aware)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 32)                        # measured: 256 threads on this small batch is 50x SLOWER than 32 (oversubscription)
+    torch.set_num_threads(cores)
     n_samples = int(seconds * 16000)
     T = n_samples // 160 + 1
     heads = {"tiny": 3, "small": 6, "base": 12}[size]
@@ -52,30 +53,32 @@ def cpu_baseline(workload, budget_clips=4, steps=2):
     sd["head.projector.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
     sd["head.projector.3.weight"] = torch.randn(256, 8192, generator=g) * 0.02
     opt = ostep.AdamW(1e-4, 0.06)
-    waves = synthetic_waveforms(budget_clips, n_samples).numpy()
+    all_waves = synthetic_waveforms(budget_clips, n_samples).numpy()
     tfm = oaug.PairTransformOracle(crop_frames=T, seed=0)
 
-    def one_step():
+    def one_step(n_clips=budget_clips):
+        waves = all_waves[:n_clips]
         lms = ofe.crop_pad_normalize(ofe.logmel(waves, dtype=np.float32), T, 0, -0.8294, 4.6230)
         v = [[], []]
-        for b in range(budget_clips):
+        for b in range(n_clips):
             c = tfm(lms[b][None])
             v[0].append(c[0]); v[1].append(c[1])
         views = [torch.from_numpy(np.stack(x)).float() for x in v]
         return ostep.bt_step(sd, views, heads, (4, 6), opt)[0]
 
     t0 = time.time()
-    one_step()                                    # warm-up (also sizes the sample: stay within ~30 s of CPU work)
-    warm = time.time() - t0
-    print(f"[bench] cpu baseline warm-up step: {warm:.1f}s on {cores} cores", file=sys.stderr, flush=True)
-    steps = max(1, min(steps, int(20.0 / max(warm, 1e-3))))
+    one_step(2)                                   # warm-up on 2 clips (also sizes the sample: stay within ~30 s of CPU work)
+    warm = (time.time() - t0) * budget_clips / 2
+    print(f"[bench] cpu baseline warm-up: ~{warm:.1f}s per {budget_clips}-clip step on {cores} threads ({avail} cores visible)",
+          file=sys.stderr, flush=True)
+    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))
     t0 = time.time()
     for _ in range(steps):
         one_step()
     dt = time.time() - t0
     return {"value": budget_clips * steps / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{budget_clips} clips x {steps} step(s) after 1 warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
-                      f"{torch.get_num_threads()} threads (oracle/: frontend + augment + fwd/bwd + AdamW)"}
+            "sample": f"{budget_clips} clips x {steps} step(s) after a 2-clip warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
+                      f"{torch.get_num_threads()} threads of {avail} visible cores (oracle/: frontend + augment + fwd/bwd + AdamW)"}
 
 
 def main():

@@ -76,11 +76,14 @@ int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const flo
  * Replaces models/mae.py:130-138 (reshape/permute, q k^T * scale, softmax, attn v, transpose/reshape).
  * qkv: bf16 [rows][ld], per row [q(C) | k(C) | v(C)], C = H*64, rows = sequences * N.  out: bf16 [rows][ldo].
  * lse: fp32 [sequences*H][N] log-sum-exp of the scaled scores (saved for backward; may be NULL in fwd).
- * bwd writes dqkv in the same packed layout as qkv (every element of the [rows][3C] block is written). */
-int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, void* out,
-                     int64_t ldo, float* lse, void* stream);
-int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, const void* out,
-                     const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream);
+ * bwd writes dqkv in the same packed layout as qkv (every element of the [rows][3C] block is written).
+ * n_query (0 = all N): only the first n_query tokens of each sequence act as queries (forward writes only those rows
+ * of `out`; backward treats dout of the other rows as zero) -- the last encoder block needs the CLS row only, because
+ * MaskedAutoencoderViT.forward returns x[:, 0] (models/mae.py:463). */
+int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, int32_t n_query, float scale,
+                     void* out, int64_t ldo, float* lse, void* stream);
+int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, int32_t n_query, float scale,
+                     const void* out, const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm1d pieces (train mode, fp32)
  * Replaces nn.BatchNorm1d at model.py:20,42 (projector / predictor, affine + ReLU) and utils/loss.py:13,17

@@ -39,8 +39,8 @@ _SIGNATURES = {
     "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P],
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, I32, I32, P],
-    "sa_attention_fwd": [P, I64, I64, I32, I32, I32, F32, P, I64, P, P],
-    "sa_attention_bwd": [P, I64, I64, I32, I32, I32, F32, P, P, I64, P, P, P],
+    "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
+    "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],
     "sa_bn_apply": [P, I64, I32, I32, P, P, P, P, I32, P, P, I64, P],
     "sa_bn_bwd_stats": [P, I32, I64, P, I64, I32, I32, P, P, P, P, I32, P, P, P],

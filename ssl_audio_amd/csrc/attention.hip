@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 
 // =====================================================================================================
 __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
-                                                          float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
+                                                          int nq, float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kimg = smem;
   char* Vimg = smem + IMG;
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
   __syncthreads();
 
   const int g = lane >> 4, c = lane & 15;
-  for (int qt = wave; qt < nkt; qt += NW_FWD) {
+  const int nqt = (nq + 15) >> 4;            // only the first nq queries of each sequence are wanted (nq = N normally)
+  for (int qt = wave; qt < nqt; qt += NW_FWD) {
     // Q fragments for this lane's query (Y operand: k = d)
     const int query = qt * 16 + c;
     bf16x8 qf[2];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
         for (int dt = 0; dt < 4; ++dt) ot[dt] = MFMA16(tr_frag(Vimg, 32 * ps, 32 * ps + 16, dt * 16, lane), pf, ot[dt]);
       }
     }
-    if (query < N) {
+    if (query < nq) {
       const float inv = 1.f / sum;
       bf16_t* orow = out + (row_base + query) * ldo + h * HD;
 #pragma unroll
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
 
 // =====================================================================================================
 __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
-                                                          float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, int ldo,
-                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
+                                                          int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                          int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qimg = smem;
   char* Kimg = smem + IMG;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
   {
     const int q = threadIdx.x;
     float dl = 0.f, ls = 0.f;
-    if (q < N && q < NMAX) {
+    if (q < nq && q < NMAX) {
       const bf16x8* po = reinterpret_cast<const bf16x8*>(o + (row_base + q) * ldo + h * HD);
       const bf16x8* pd = reinterpret_cast<const bf16x8*>(dout + (row_base + q) * ldo + h * HD);
 #pragma unroll
@@ -206,12 +207,22 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
   const int g = lane >> 4, c = lane & 15;
 
   // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
+  const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
   for (int qt = wave; qt < nkt; qt += NW_BWD) {
     const int query = qt * 16 + c;
+    if (qt >= nqt) {                                       // dQ of an un-queried tile is exactly zero
+      if (query < N) {
+        bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
+        const bf16x4 z = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = z;
+      }
+      continue;
+    }
     const bf16x8 qf0 = row_frag(Qimg, qt * 16, 0, lane), qf1 = row_frag(Qimg, qt * 16, 1, lane);
     const bf16x8 df0 = row_frag(Dimg, qt * 16, 0, lane), df1 = row_frag(Dimg, qt * 16, 1, lane);
     const float lq = lse_s[query], dq_delta = del_s[query];
-    const bool qvalid = query < N;
+    const bool qvalid = query < nq;
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(tr_frag(Kimg, 32 * ps, 32 * ps + 16, dt * 16, lane), dsf, acc[dt]);
     }
-    if (qvalid) {
+    if (query < N) {
       bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int qs = 0; qs < nks; ++qs) {
+    for (int qs = 0; qs < nqs; ++qs) {
       f32x4 pp[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int query = qt * 16 + 4 * g + r;
-          const float p = (kvalid && query < N) ? __expf(sv[r] * scale - lse_s[query]) : 0.f;
+          const float p = (kvalid && query < nq) ? __expf(sv[r] * scale - lse_s[query]) : 0.f;
           pp[u][r] = p;
           ds[u][r] = p * (dp[r] - del_s[query]) * scale;
         }
@@ -306,8 +317,9 @@ static int attn_check(const char* who, const void* qkv, int64_t rows, int64_t ld
   return 0;
 }
 
-extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, void* out,
-                                int64_t ldo, float* lse, void* stream) {
+extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, int32_t n_query, float scale,
+                                void* out, int64_t ldo, float* lse, void* stream) {
+  if (n_query <= 0 || n_query > N) n_query = N;
   if (attn_check("sa_attention_fwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && ldo >= C && ldo % 4 == 0, "sa_attention_fwd: bad output");
   static bool configured = false;
@@ -316,14 +328,15 @@ extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32
     configured = true;
   }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(256), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
-                     (bf16_t*)out, (int)ldo, lse);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(256), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+                     scale, (bf16_t*)out, (int)ldo, lse);
   SA_LAUNCH_CHECK("sa_attention_fwd");
   return 0;
 }
 
-extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, float scale, const void* out,
-                                const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream) {
+extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, int32_t n_query, float scale,
+                                const void* out, const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream) {
+  if (n_query <= 0 || n_query > N) n_query = N;
   if (attn_check("sa_attention_bwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && dout && lse && dqkv && ldo >= C && ldo % 8 == 0, "sa_attention_bwd: bad args");
   SA_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)out & 15) == 0, "sa_attention_bwd: out/dout must be 16-byte aligned");
@@ -334,7 +347,7 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
     configured = true;
   }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, scale,
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query, scale,
                      (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   SA_LAUNCH_CHECK("sa_attention_bwd");
   return 0;

@@ -169,6 +169,80 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved):
     return dx, dx_16
 
 
+def block_forward_cls(x, p, H, N, eps, save):
+    """LAST block when only the CLS row of its output is consumed (MaskedAutoencoderViT.forward returns x[:, 0],
+    models/mae.py:463): every token still feeds K and V, but queries, proj and the MLP are needed for row 0 of each
+    sequence only -- S rows instead of S*N for 18/24 of the block's linear FLOPs.  Mathematically identical.
+    Returns the compact [S, d] fp32 output rows."""
+    M, d = x.shape
+    S = M // N
+    dev = x.device
+    W = BF16_WEIGHTS.get
+    h1 = torch.empty(M, d, dtype=BF16, device=dev)
+    mean1, rstd1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, p.n1w, p.n1b, eps, y_bf16=h1, mean=mean1, rstd=rstd1)
+    qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
+    qkv_bias = torch.cat((p.qb.detach(), torch.zeros_like(p.vb), p.vb.detach()))
+    ops.gemm(h1, W(p.wqkv), bias=qkv_bias, out_bf16=qkv)
+    ao = torch.zeros(M, d, dtype=BF16, device=dev)            # only the CLS rows are written
+    lse = torch.zeros(S * H, N, device=dev)
+    ops.attention_fwd(qkv, H, N, (d // H) ** -0.5, ao, lse, n_query=1)
+    xc, aoc = x.view(S, N * d)[:, :d], ao.view(S, N * d)[:, :d]      # CLS rows as strided [S, d] views
+    x2 = torch.empty(S, d, device=dev)
+    ops.gemm(aoc, W(p.wp), bias=p.bp.detach(), residual=xc, out_f32=x2)
+    h2 = torch.empty(S, d, dtype=BF16, device=dev)
+    mean2, rstd2 = torch.empty(S, device=dev), torch.empty(S, device=dev)
+    ops.layernorm_fwd(x2, p.n2w, p.n2b, eps, y_bf16=h2, mean=mean2, rstd=rstd2)
+    hidden = p.w1.shape[0]
+    pre = torch.empty(S, hidden, dtype=BF16, device=dev) if save is not None else None
+    a = torch.empty(S, hidden, dtype=BF16, device=dev)
+    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=1, aux_out=pre, out_bf16=a)
+    x3 = torch.empty(S, d, device=dev)
+    ops.gemm(a, W(p.w2), bias=p.b2.detach(), residual=x2, out_f32=x3)
+    if save is not None:
+        save.append((x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a))
+    return x3
+
+
+def block_backward_cls(dx3, dx3_16, p, g, H, N, saved):
+    """Backward of block_forward_cls: dx3 / dx3_16 are the [S, d] gradients of the CLS output rows."""
+    x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a = saved
+    M, d = x.shape
+    S = M // N
+    dev = x.device
+    W = BF16_WEIGHTS.get
+    _wgrad(dx3_16, a, g.w2)
+    ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
+    dpre = torch.empty_like(pre)
+    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre)
+    _wgrad(dpre, h2, g.w1)
+    ops.colsum_bf16(dpre, g.b1, accumulate=True)
+    dh2 = torch.empty(S, d, dtype=BF16, device=dev)
+    ops.gemm(dpre, W(p.w1), b_kmajor=False, out_bf16=dh2)
+    dx2 = torch.zeros(M, d, device=dev)                       # residual-stream gradient: non-zero on the CLS rows only
+    dx2c = dx2.view(S, N * d)[:, :d]
+    dx2_16 = torch.empty(S, d, dtype=BF16, device=dev)
+    ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_f32=dx2c, dgamma=g.n2w, dbeta=g.n2b)
+    ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_bf16=dx2_16)          # bf16 copy (compact rows; S x d, trivial)
+    aoc = ao.view(S, N * d)[:, :d]
+    _wgrad(dx2_16, aoc, g.wp)
+    ops.colsum_bf16(dx2_16, g.bp, accumulate=True)
+    dao = torch.zeros(M, d, dtype=BF16, device=dev)
+    ops.gemm(dx2_16, W(p.wp), b_kmajor=False, out_bf16=dao.view(S, N * d)[:, :d])
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv, n_query=1)
+    _wgrad(dqkv, h1, g.wqkv)
+    ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
+    ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
+    dh1 = dao
+    ops.gemm(dqkv, W(p.wqkv), b_kmajor=False, out_bf16=dh1)
+    del dqkv
+    dx = torch.empty(M, d, device=dev)
+    dx_16 = torch.empty(M, d, dtype=BF16, device=dev)
+    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b)
+    return dx, dx_16
+
+
 class EncoderFn(torch.autograd.Function):
     """tokens [S, N, d] fp32 (CLS + patch tokens, positional terms already added) -> transformer blocks -> final
     LayerNorm.  Output: CLS latent [S, d] (pool='cls'), mean of patch tokens [S, d] (pool='mean') or the whole
@@ -183,20 +257,22 @@ class EncoderFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         save = [] if need_grad else None
         x = tokens.detach().reshape(S * N, d)
-        for bp in blocks:
+        cls_prune = pool == "cls" and n_blocks >= 1 and N > 1
+        for bp in (blocks[:-1] if cls_prune else blocks):
             x = block_forward(x, bp, H, N, eps, save)
         dev = x.device
         if pool == "cls":
-            rows = x.view(S, N * d)[:, :d]
+            rows = block_forward_cls(x, blocks[-1], H, N, eps, save) if cls_prune else x.view(S, N * d)[:, :d]
             out = torch.empty(S, d, device=dev)
             mean, rstd = torch.empty(S, device=dev), torch.empty(S, device=dev)
             ops.layernorm_fwd(rows, nw, nb, eps, y_f32=out, mean=mean, rstd=rstd)
+            x = rows
         else:
             y = torch.empty(S * N, d, device=dev)
             mean, rstd = torch.empty(S * N, device=dev), torch.empty(S * N, device=dev)
             ops.layernorm_fwd(x, nw, nb, eps, y_f32=y, mean=mean, rstd=rstd)
             out = y.view(S, N, d)[:, 1:].mean(dim=1).contiguous() if pool == "mean" else y.view(S, N, d)
-        ctx.cfg = (S, N, d, H, pool, n_blocks)
+        ctx.cfg = (S, N, d, H, pool, n_blocks, cls_prune)
         ctx.saved = save
         ctx.final = (x, mean, rstd)
         ctx.params = params
@@ -204,7 +280,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        S, N, d, H, pool, n_blocks = ctx.cfg
+        S, N, d, H, pool, n_blocks, cls_prune = ctx.cfg
         params = ctx.params
         x, mean, rstd = ctx.final
         dev = x.device
@@ -220,10 +296,14 @@ class EncoderFn(torch.autograd.Function):
         gnw, gnb = gz[13 * n_blocks], gz[13 * n_blocks + 1]
         dout = dout.contiguous().float()
         M = S * N
-        if pool == "cls":
+        if pool == "cls" and cls_prune:
+            dx = torch.empty(S, d, device=dev)                 # gradient of the CLS rows only (x is the compact [S, d] output)
+            dx16 = torch.empty(S, d, dtype=BF16, device=dev)
+            ops.layernorm_bwd(dout, x, nw, mean, rstd, dx_f32=dx, dx_bf16=dx16, dgamma=gnw, dbeta=gnb)
+        elif pool == "cls":
             dx = torch.zeros(M, d, device=dev)
             dx16 = torch.zeros(M, d, dtype=BF16, device=dev)
-            ops.layernorm_bwd(dout, x.view(S, N * d)[:, :d], nw, mean, rstd, dx_f32=dx.view(S, N * d)[:, :d],
+            ops.layernorm_bwd(dout, x, nw, mean, rstd, dx_f32=dx.view(S, N * d)[:, :d],      # x: strided CLS-row view
                               dx_bf16=dx16.view(S, N * d)[:, :d], dgamma=gnw, dbeta=gnb)
         else:
             if pool == "mean":
@@ -238,7 +318,10 @@ class EncoderFn(torch.autograd.Function):
         for i in reversed(range(n_blocks)):
             bp = BlockParams(params[13 * i:13 * (i + 1)])
             bg = BlockParams(gz[13 * i:13 * (i + 1)])
-            dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i])
+            if cls_prune and i == n_blocks - 1:
+                dx, dx16 = block_backward_cls(dx, dx16, bp, bg, H, N, ctx.saved[i])
+            else:
+                dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i])
             ctx.saved[i] = None
             if BLOCK_DONE_HOOK is not None:
                 BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])

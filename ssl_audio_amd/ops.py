@@ -83,10 +83,18 @@ def pick_split_k(M, N, K, cu_count=256):
     """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ksteps = (K + 63) // 64
-    split = 1
-    while tiles * split < 2 * cu_count and split * 2 <= ksteps // 4:
-        split *= 2
-    return split
+    slots = 2 * cu_count                   # the 128^2 kernel runs two workgroups per CU
+    if tiles >= slots or ksteps < 16:
+        return 1
+    # time ~ (rounds of resident workgroups) x (K-iterations per workgroup + fill/epilogue): a split that leaves the last
+    # round nearly empty (e.g. 576 workgroups on 512 slots) costs a whole extra round, so search instead of doubling
+    best, best_cost = 1, None
+    for s in range(1, min(32, ksteps // 4) + 1):
+        rounds = -(-tiles * s // slots)
+        cost = rounds * (-(-ksteps // s) + 8)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s, cost
+    return best
 
 
 def cast_bf16(src, dst=None):
@@ -126,19 +134,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=N
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention_fwd(qkv, H, N, scale, out, lse=None):
+def attention_fwd(qkv, H, N, scale, out, lse=None, n_query=0):
     rows, w, ld = _rows(_req(qkv, BF16, "qkv"), "qkv")
     Cdim = w // 3
-    check(lib().sa_attention_fwd(_p(qkv), rows, ld, Cdim, H, N, float(scale), _p(_req(out, BF16, "out")), _rows(out, "out")[2],
-                                 _p(lse), _stream()), "sa_attention_fwd")
+    check(lib().sa_attention_fwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(_req(out, BF16, "out")),
+                                 _rows(out, "out")[2], _p(lse), _stream()), "sa_attention_fwd")
 
 
-def attention_bwd(qkv, H, N, scale, out, dout, lse, dqkv):
+def attention_bwd(qkv, H, N, scale, out, dout, lse, dqkv, n_query=0):
     rows, w, ld = _rows(_req(qkv, BF16, "qkv"), "qkv")
     Cdim = w // 3
     if _rows(dqkv, "dqkv")[2] != ld or _rows(dout, "dout")[2] != _rows(out, "out")[2]:
         raise ValueError("attention_bwd: dqkv/qkv and dout/out must share leading dimensions")
-    check(lib().sa_attention_bwd(_p(qkv), rows, ld, Cdim, H, N, float(scale), _p(out), _p(_req(dout, BF16, "dout")), _rows(out, "out")[2],
+    check(lib().sa_attention_bwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(out), _p(_req(dout, BF16, "dout")), _rows(out, "out")[2],
                                  _p(_req(lse, F32, "lse")), _p(_req(dqkv, BF16, "dqkv")), _stream()), "sa_attention_bwd")
 
 
