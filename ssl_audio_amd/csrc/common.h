@@ -59,10 +59,23 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
 
-// exact-erf GELU (timm Mlp act_layer=nn.GELU, models/mae.py:155) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (timm Mlp act_layer=nn.GELU, models/mae.py:155) and its derivative.  erf is evaluated branch-free with
+// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 + one fast-exp ulp): libm's erff is ~40 instructions with divergent
+// branches, and 64 unrolled copies of it in a GEMM epilogue cost 150 VGPRs and spills; the result is rounded to bf16
+// (8 significant bits) right afterwards, so the two are indistinguishable downstream.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float r = 1.0f - poly * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
