@@ -19,7 +19,7 @@ constexpr int HD = 64;          // head dim
 constexpr int NMAX = 256;       // max tokens per sequence
 constexpr int IMG = NMAX * HD * 2;  // bytes of one [256][64] bf16 LDS image
 constexpr int NW_FWD = 4;           // waves per workgroup, forward
-constexpr int NW_BWD = 8;           // backward: 133 KiB of LDS allows one workgroup per CU, so give it 8 waves to hide latency
+constexpr int NW_BWD = 8;           // backward: 8 waves per workgroup, two workgroups per CU (66 KiB of LDS each)
 
 // ---- LDS image: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7)
 __device__ __forceinline__ int img_off(int row, int col) {  // col in elements, multiple of 4
@@ -55,6 +55,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int lo, int hi, int c
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
+}
+
+// row fragment straight from global memory (same lane mapping as row_frag): M[row0 + (lane&15)][col0 + 32*ks + 8*(lane>>4) .. +7]
+__device__ __forceinline__ bf16x8 row_frag_global(__amdgpu_buffer_rsrc_t rsrc, int ld, int row0, int col0, int ks, int lane) {
+  const uint32_t voff = ((uint32_t)(row0 + (lane & 15)) * (uint32_t)ld + (uint32_t)(col0 + 32 * ks + 8 * (lane >> 4))) * 2u;
+  auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+  return __builtin_bit_cast(bf16x8, raw);
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
@@ -157,15 +164,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // =====================================================================================================
-__global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+__global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qimg = smem;
-  char* Kimg = smem + IMG;
-  char* Vimg = smem + 2 * IMG;
-  char* Dimg = smem + 3 * IMG;                       // dO
-  float* lse_s = reinterpret_cast<float*>(smem + 4 * IMG);
+  // Two 32 KiB images at a time (66 KiB with the statistics -> two workgroups per CU): K,V during pass A, then the same
+  // LDS is re-staged with Q,dO for pass B.  The operand that is NOT in LDS is read as 16-byte row fragments from global.
+  char* Kimg = smem;
+  char* Vimg = smem + IMG;
+  char* Qimg = smem;                                 // pass B reuses the two images
+  char* Dimg = smem + IMG;                           // dO
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * IMG);
   float* del_s = lse_s + NMAX;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -177,10 +186,8 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
   const int nkt = (N + 15) >> 4;
   const int nks = (N + 31) >> 5;
   const int nrows = nks * 32;
-  stage_rows(rs, Qimg, ld, h * HD, nrows, wave, lane, NW_BWD);
   stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
-  stage_rows(rd, Dimg, ldo, h * HD, nrows, wave, lane, NW_BWD);
   // delta[q] = sum_d dO[q][d] * O[q][d]  (straight from global, one query row per thread), lse -> LDS
   {
     const int q = threadIdx.x;
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
       }
       continue;
     }
-    const bf16x8 qf0 = row_frag(Qimg, qt * 16, 0, lane), qf1 = row_frag(Qimg, qt * 16, 1, lane);
-    const bf16x8 df0 = row_frag(Dimg, qt * 16, 0, lane), df1 = row_frag(Dimg, qt * 16, 1, lane);
+    const bf16x8 qf0 = row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), qf1 = row_frag_global(rs, ld, qt * 16, h * HD, 1, lane);
+    const bf16x8 df0 = row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), df1 = row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane);
     const float lq = lse_s[query], dq_delta = del_s[query];
     const bool qvalid = query < nq;
     f32x4 acc[4];
@@ -258,11 +265,16 @@ __global__ __launch_bounds__(64 * NW_BWD, 1) void attn_bwd_kernel(const bf16_t* 
   }
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
+  __syncthreads();                                   // every wave is done reading the K / V images
+  stage_rows(rs, Qimg, ld, h * HD, nqs * 32, wave, lane, NW_BWD);
+  stage_rows(rd, Dimg, ldo, h * HD, nqs * 32, wave, lane, NW_BWD);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
-    const bf16x8 kf0 = row_frag(Kimg, kt * 16, 0, lane), kf1 = row_frag(Kimg, kt * 16, 1, lane);
-    const bf16x8 vf0 = row_frag(Vimg, kt * 16, 0, lane), vf1 = row_frag(Vimg, kt * 16, 1, lane);
+    const bf16x8 kf0 = row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), kf1 = row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane);
+    const bf16x8 vf0 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), vf1 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane);
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -340,7 +352,7 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
   if (attn_check("sa_attention_bwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && dout && lse && dqkv && ldo >= C && ldo % 8 == 0, "sa_attention_bwd: bad args");
   SA_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)out & 15) == 0, "sa_attention_bwd: out/dout must be 16-byte aligned");
-  const int lds = 4 * IMG + 2 * NMAX * (int)sizeof(float);
+  const int lds = 2 * IMG + 2 * NMAX * (int)sizeof(float);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -365,3 +365,28 @@ def test_token_ops(dev):
     ops.scatter_add_rows(dst, 6 * d, 1, idx, back, N * d, 1, S, d)
     chk = torch.zeros(S, N - 1, d, device=dev).scatter_add_(1, idx.long().unsqueeze(-1).expand(-1, -1, d), ref)
     assert torch.equal(back[:, 1:], chk)
+
+
+def test_attention_n_query(dev):
+    """n_query = 1 (the CLS-only last block): forward equals row 0 of the full result; backward equals the full kernel fed
+    with an upstream gradient that is zero outside row 0 (dQ rows > 0 come out exactly zero)."""
+    S, H, N = 3, 2, 249
+    C_ = 64 * H
+    qkv = bf(rnd((S * N, 3 * C_), 40)).to(dev)
+    full = torch.empty(S * N, C_, device=dev, dtype=torch.bfloat16); lse_full = torch.empty(S * H, N, device=dev)
+    ops.attention_fwd(qkv, H, N, 0.125, full, lse_full)
+    part = torch.zeros(S * N, C_, device=dev, dtype=torch.bfloat16); lse = torch.zeros(S * H, N, device=dev)
+    ops.attention_fwd(qkv, H, N, 0.125, part, lse, n_query=1)
+    rows0 = torch.arange(S, device=dev) * N
+    assert torch.equal(part[rows0], full[rows0]) and float(part.float().abs().sum()) == float(part[rows0].float().abs().sum())
+    assert torch.equal(lse[:, 0], lse_full[:, 0])
+    dout = torch.zeros(S * N, C_, device=dev, dtype=torch.bfloat16)
+    dout[rows0] = bf(rnd((S, C_), 41)).to(dev)
+    ref = torch.empty(S * N, 3 * C_, device=dev, dtype=torch.bfloat16)
+    ops.attention_bwd(qkv, H, N, 0.125, full, dout, lse_full, ref)
+    got = torch.full((S * N, 3 * C_), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.attention_bwd(qkv, H, N, 0.125, part, dout, lse, got, n_query=1)
+    assert torch.isfinite(got.float()).all()
+    assert rel_err(got, ref) < 1e-6
+    mask = torch.ones(S * N, dtype=torch.bool, device=dev); mask[rows0] = False
+    assert float(got[mask][:, :C_].float().abs().max()) == 0.0
