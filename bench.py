@@ -99,6 +99,7 @@ def main():
     rank, local, world = sdist.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = local % max(torch.cuda.device_count(), 1)              # (lets several gloo ranks rehearse on a 1-GPU box)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.lib()                                                      # fail loudly if the HIP library is missing

@@ -154,6 +154,10 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4&
 constexpr int EPI_STRIDE = 144;                 // bytes per staged row: 64 bf16 + 16 B pad (16-byte aligned rows)
 constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
 
+// SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by (row & 7),
+// exactly 8 KiB per wave -- four waves fit one 32 KiB pipeline stage (the persistent kernel stages its epilogue in the
+// stage it has just finished reading while the other stage already receives the next tile).
+template <bool SWZ>
 __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32x4 (&v)[4][4], char* wlds, bf16_t* dst, int64_t ld,
                                                   int m_base, int n_base, bool remap, int lane) {
   const int g = lane >> 4, c = lane & 15;
@@ -162,14 +166,19 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bf16x4 h = {f2bf(v[i][j][0]), f2bf(v[i][j][1]), f2bf(v[i][j][2]), f2bf(v[i][j][3])};
-      *reinterpret_cast<bf16x4*>(wlds + (i * 16 + c) * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
+      const int row = i * 16 + c;
+      if constexpr (SWZ)
+        *reinterpret_cast<bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = h;
+      else
+        *reinterpret_cast<bf16x4*>(wlds + row * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
     }
   const int ch = lane & 7;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int r = it * 8 + (lane >> 3);
     const int m = m_base + r;
-    const uint4 val = *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
+    const uint4 val = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
+                          : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
     if (m < p.M) {
       const int64_t orow = (remap && p.row_group > 0) ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
       *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
@@ -177,6 +186,7 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32
   }
 }
 
+template <bool SWZ = false>
 __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
   const int g = lane >> 4, c = lane & 15;
   const bool fast = (n_base + 64 <= p.N) &&
@@ -206,7 +216,7 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
     }
   }
   if (p.act == 1) {
-    if (p.aux_out) staged_store_bf16(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
+    if (p.aux_out) staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -244,7 +254,7 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
     }
     __builtin_amdgcn_sched_barrier(0);   // keep each 16-row group's loads/stores together: hoisting all 16 residual loads spills
   }
-  if (p.out_bf16) staged_store_bf16(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
+  if (p.out_bf16) staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
 }
 
 template <bool A_KM, bool B_KM, bool SWAP>
@@ -758,6 +768,125 @@ int launch192(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
+// =====================================================================================================
+// Persistent 128 x 128 x 64 kernel (forward / dgrad, no split-K): a workgroup walks tiles lid, lid + grid, ...  The first
+// K-tile of the NEXT output tile is requested during the last K-iteration of the current one and lands while the epilogue
+// runs (which stages through the pipeline stage that was just consumed), so neither the pipeline fill nor the store tail
+// of a 12-iteration (K = 768) tile is exposed any more.
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_persist_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | B tile]
+  constexpr int STAGE = 2 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  constexpr int GM = 8;
+  const int group_sz = GM * p.tiles_n;
+  auto coords = [&](int t, int& m0, int& n0) {
+    const int grp = t / group_sz, within = t - grp * group_sz;
+    const int gm = min(GM, p.tiles_m - grp * GM);
+    m0 = (grp * GM + within % gm) * BM;
+    n0 = (within / gm) * BN;
+  };
+  const int ksteps = p.K / BK + ((p.K % BK) ? 1 : 0);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  int t = lid;
+  if (t >= ntiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+  stage_tile<A_KM>(ra, smem, p.lda, m0, 0, wave, lane);
+  stage_tile<B_KM>(rb, smem + TILE_BYTES, p.ldb, n0, 0, wave, lane);
+  int cur = 0;
+  while (true) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first K-tile of this output tile (and the previous epilogue's stores)
+    __builtin_amdgcn_s_barrier();
+    const int tnext = t + nwg;
+    const bool has_next = tnext < ntiles;
+    int m0n = 0, n0n = 0;
+    if (has_next) coords(tnext, m0n, n0n);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ksteps; ++kt) {
+      char* nxt = smem + (cur ^ 1) * STAGE;
+      const bool more = kt + 1 < ksteps;
+      if (more) {
+        stage_tile<A_KM>(ra, nxt, p.lda, m0, (kt + 1) * BK, wave, lane);
+        stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0, (kt + 1) * BK, wave, lane);
+      } else if (has_next) {
+        stage_tile<A_KM>(ra, nxt, p.lda, m0n, 0, wave, lane);
+        stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0n, 0, wave, lane);
+      }
+      const char* ta = smem + cur * STAGE;
+      const char* tb = ta + TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KM>(ta, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
+    }
+    // every wave has consumed stage `cur` (its MFMAs needed the fragments): it becomes the epilogue's staging area while
+    // stage cur^1 is receiving the next tile.  Raw barrier: the pending LDS-DMA must NOT be drained here.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    wave_epilogue_64x64<true>(p, acc, m0 + wr * 64, n0 + wc * 64, smem + cur * STAGE + wave * 8192, lane);
+    if (!has_next) break;
+    t = tnext; m0 = m0n; n0 = n0n;
+    cur ^= 1;
+  }
+}
+
+template <bool A_KM, bool B_KM>
+int launch_persist(GemmParams p, hipStream_t stream) {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: cannot query the device");
+      return 2;
+    }
+    slots = 2 * prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * TILE_BYTES);
+  }
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * TILE_BYTES);
+    configured = true;
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = ntiles < slots ? ntiles : slots;
+  hipLaunchKernelGGL((gemm_persist_kernel<A_KM, B_KM>), dim3(grid), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(persistent)");
+  return 0;
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 int launch(const GemmParams& p, hipStream_t stream) {
   const int nwg = p.tiles_m * p.tiles_n * p.split_k;
@@ -879,8 +1008,14 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   // Measured on the ViT-B shapes (scripts/bench_gemm.py, random operands): the 128^2 kernel (mode 1, two 4-wave
   // workgroups per CU) beats the 192x128 (mode 4), 256x128 three-stage (mode 3) and 256^2 (mode 2) variants at K = 768;
   // those stay selectable through SA_GEMM_TILE for experiments and are parity-tested.
-  const char mode = force ? force[0] : '1';
+  const char mode = force ? force[0] : '1';   // (mode 5, persistent, measured equal to mode 1: 3.51 vs 3.46 ms per layer)
   (void)big;
+  if (mode == '5' && a->split_k == 1) {
+    if (a->a_kmajor && a->b_kmajor) return launch_persist<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch_persist<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch_persist<false, true>(p, stream);
+    return launch_persist<false, false>(p, stream);
+  }
   if (mode == '4' && a->split_k == 1 && a->a_kmajor) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 192 tile");
     return a->b_kmajor ? launch192<true>(p, stream) : launch192<false>(p, stream);

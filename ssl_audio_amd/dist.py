@@ -37,10 +37,11 @@ def init_from_env(backend=None):
         return 0, 0, 1
     rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["WORLD_SIZE"])
     if not dist.is_initialized():
+        backend = os.environ.get("SA_DIST_BACKEND", backend)    # e.g. gloo to rehearse several ranks on one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend)
     return rank, local, world
 

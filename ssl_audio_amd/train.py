@@ -112,17 +112,27 @@ class GradSync:
         """engine.BLOCK_DONE_HOOK: the gradients of `params` are final -> reduce their flat range now."""
         if self.world == 1:
             return
-        lo, hi = None, None
+        spans = []
         for p in params:
             ent = engine.GRAD_SINK.get(id(p))
             if ent is None or ent[0]() is not p:
                 continue
             g = ent[1]
             a = (g.data_ptr() - self.flat.grads.data_ptr()) // 4
-            lo = a if lo is None else min(lo, a)
-            hi = a + g.numel() if hi is None else max(hi, a + g.numel())
-        if lo is not None:
-            self._launch(lo, hi)
+            spans.append((a, a + (g.numel() + 7) // 8 * 8))
+        # a block's parameters sit in two places of the flat buffer (decayed weights | un-decayed vectors): reduce each
+        # contiguous run on its own -- a single min..max range would sweep up other layers' unfinished gradients
+        spans.sort()
+        run = None
+        for a, b in spans:
+            if run is not None and a <= run[1]:
+                run = (run[0], max(run[1], b))
+            else:
+                if run is not None:
+                    self._launch(run[0], min(run[1], self.flat.n_train))
+                run = (a, b)
+        if run is not None:
+            self._launch(run[0], min(run[1], self.flat.n_train))
 
     def _launch(self, lo, hi):
         self._ready_ranges.append((lo, hi))
@@ -211,8 +221,10 @@ class BarlowTwinsTrainer:
 
     # ------------------------------------------------------------------ one optimisation step
     def step(self, batch):
-        cfg = self.cfg
-        views = self.make_views(batch)
+        return self.step_views(self.make_views(batch))
+
+    def step_views(self, views):
+        """One optimisation step on two already-augmented views [B,1,F,T] (what train_one_epoch receives from its loader)."""
         self.flat.zero_grad()
         if self.mode == "bt":
             z = self.online(views, ncrops=2)

@@ -121,11 +121,26 @@ def _worker_body(rank, world, port, q):
         off = [20, 30, 60][k]
         engine.GRAD_SINK[id(p)] = (weakref.ref(p), flat.grads[off:off + 10])
     sync = GradSync(flat)
-    sync.block_done(params[:2])
-    sync.block_done(params[2:])
-    sync.finish()
-    expect = torch.arange(100, dtype=torch.float32) * sum(range(1, world + 1))
-    ok_sync = torch.equal(flat.grads, expect)
+    sync.block_done(params[:2])                             # one contiguous run [20, 40)
+    sync.block_done([params[2], params[0]])                 # scattered: [60, 70) and (again, idempotent ranges are NOT allowed) -> see below
+    ok_sync = False
+    # a block whose parameters are scattered must NOT sweep up what lies between them: gradients written there later
+    # (by the remaining backward) have to be reduced exactly once, in finish()
+    flat2 = Flat()
+    flat2.n_train = 96
+    flat2.grads = torch.zeros(96)
+    q0, q1 = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
+    engine.GRAD_SINK[id(q0)] = (weakref.ref(q0), flat2.grads[0:8])
+    engine.GRAD_SINK[id(q1)] = (weakref.ref(q1), flat2.grads[80:88])
+    flat2.grads[0:8] = rank + 1.0
+    flat2.grads[80:88] = 10.0 * (rank + 1)
+    sync2 = GradSync(flat2)
+    sync2.block_done([q0, q1])
+    flat2.grads[8:80] = 100.0 * (rank + 1)                  # "later layers" finish after the hook fired
+    sync2.finish()
+    tot = sum(range(1, world + 1))
+    ok_sync = (torch.all(flat2.grads[0:8] == tot) and torch.all(flat2.grads[80:88] == 10.0 * tot)
+               and torch.all(flat2.grads[8:80] == 100.0 * tot) and torch.all(flat2.grads[88:] == 0)).item()
     q.put((rank, ok, ok_lit, ok_bn, ok_sync, float(loss), float(lit_loss)))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,106 @@
+"""Data-parallel step on the real kernels: 2 ranks (gloo, both on cuda:0 -- RCCL refuses two ranks on one device) each
+take half of a batch and must end up with the parameters a single process gets on the whole batch
+(global-batch-exact semantics: SyncBN statistics, cross-correlation all-reduce, gradient SUM)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(world_batch, rank, world):
+    from ssl_audio_amd import hyperparameters as hp
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    dev = torch.device("cuda:0")
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=world_batch, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128)
+    tr = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=world_batch // world, clip_samples=15200, seed=0)
+    g = torch.Generator().manual_seed(7)
+    views = [torch.randn(world_batch, 1, 64, 96, generator=g), torch.randn(world_batch, 1, 64, 96, generator=g)]
+    sl = slice(rank * world_batch // world, (rank + 1) * world_batch // world)
+    return tr, [v[sl].to(dev).contiguous() for v in views]
+
+
+def _grads(tr):
+    """Gradients left in the flat buffer after the step (already summed over ranks)."""
+    from ssl_audio_amd import engine
+    named = dict(tr.online.named_parameters())
+    return {k: engine.GRAD_SINK[id(named[k])][1].detach().float().cpu().numpy().copy() for k in KEYS if k in named}
+
+
+KEYS = ["backbone.encoder.encoder.cls_token", "backbone.encoder.encoder.blocks.0.attn.qkv.weight",
+        "backbone.encoder.encoder.blocks.11.mlp.fc2.weight", "head.projector.0.weight", "head.projector.1.weight",
+        "head.projector.3.weight", "head.projector.1.running_var"]
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          SA_DIST_BACKEND="gloo")
+        from ssl_audio_amd import dist as sdist
+        sdist.init_from_env("gloo")
+        tr, views = _make(16, rank, world)
+        loss = float(tr.step_views(views))
+        torch.cuda.synchronize()
+        sd = tr.online.state_dict()
+        q.put((rank, loss, {k: sd[k].detach().float().cpu().numpy() for k in KEYS}, None, _grads(tr)))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, repr(e) + traceback.format_exc()))
+
+
+def test_two_ranks_equal_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[3] is None, r[3]
+    # single process on the whole batch (this process)
+    tr, views = _make(16, 0, 1)
+    p0 = {k: tr.online.state_dict()[k].detach().float().cpu().numpy().copy() for k in KEYS}
+    loss = float(tr.step_views(views))
+    torch.cuda.synchronize()
+    sd = tr.online.state_dict()
+    g_ref = _grads(tr)
+    for r in res:                                                        # summed rank gradients == single-process gradients
+        for k, g in g_ref.items():
+            err = np.linalg.norm(r[4][k] - g) / (np.linalg.norm(g) + 1e-30)
+            assert err < 3e-2, (k, err)
+    assert abs(res[0][1] - res[1][1]) < 1e-6 * abs(loss) + 1e-6          # both ranks hold the same (global) loss
+    assert abs(res[0][1] - loss) / abs(loss) < 2e-3                      # == single-process loss (bf16 summation-order noise)
+    lr = tr.lr
+    for k in KEYS:
+        ref = sd[k].detach().float().cpu().numpy()
+        for r in res:
+            if "running" in k:
+                np.testing.assert_allclose(r[2][k], ref, rtol=2e-2, atol=1e-3, err_msg=k)
+            else:
+                # after one AdamW step every element moved by <= lr; agreement up to sign flips of near-zero gradients
+                moved = np.abs(ref - p0[k]).max()
+                assert 0 < moved <= 1.01 * lr + 1e-9, (k, moved)
+                frac_same = np.mean(np.abs(r[2][k] - ref) <= 0.25 * lr)
+                assert frac_same > 0.7, (k, frac_same)        # Adam turns near-zero gradients into +-lr: sign flips are expected
+        np.testing.assert_array_equal(res[0][2][k], res[1][2][k])        # replicas stay bit-identical across ranks
