@@ -155,14 +155,20 @@ def main():
 
     if rank == 0:
         clips_per_s = B * world * args.steps / dt
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
-        gemm_flop = sum(fl for _, _, fl, _ in prof)
+        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in prof)
+        gemm_flop = sum(fl for _, _, fl, *_ in prof)
         n_launch = max(len(prof), 1)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         by_kind = {}
-        for e0, e1, fl, kind in prof:
+        for e0, e1, fl, kind, _ in prof:
             ms, f = by_kind.get(kind, (0.0, 0.0))
             by_kind[kind] = (ms + e0.elapsed_time(e1), f + fl)
+        alg_bytes = sum(t[4] for t in prof) / n_launch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath) and args.workload == "vit_base_bt_10s" and B == 128:
+            # HBM bytes per GEMM launch from rocprofv3 PMC passes of this same command (scripts/collect_traffic.sh)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
             "metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +180,8 @@ def main():
                        "loss": round(loss_val, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 16x16x32, all layouts: fwd NT / dgrad NN / wgrad TN)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "algorithmic_bytes_per_launch": round(alg_bytes),
                          "launches": len(prof), "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                          "gemm_share_of_step": round(gemm_ms / (dt * 1e3), 4),
                          "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0},

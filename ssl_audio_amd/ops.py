@@ -76,7 +76,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
     e1.record()
     kind = ("NT" if b_kmajor else "NN") if a_kmajor else ("TT" if b_kmajor else "TN")
-    GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else "")))
+    nbytes = 2.0 * (M * K + N * K) + (4.0 * M * N if out_f32 is not None else 0.0) + (2.0 * M * N if out_bf16 is not None else 0.0) \
+        + (2.0 * M * N if (aux_in is not None or aux_out is not None) else 0.0) + (4.0 * M * N if residual is not None and not res_mod else 0.0)
+    GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes))
 
 
 def pick_split_k(M, N, K, cu_count=256):
