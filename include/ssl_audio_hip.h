@@ -54,6 +54,7 @@ typedef struct SaGemmArgs {
   int32_t split_k;              /* >= 1.  > 1: K is split over workgroups and partial tiles are atomically
                                    ADDED into out_f32 (caller zeroes / owns accumulation); only alpha is applied */
   int32_t accumulate;           /* split_k == 1 only: out_f32 += v instead of = v */
+  int32_t tile256;              /* split_k > 1 only: use the 256 x 256 tile (one workgroup per CU) instead of 128 x 128 */
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 
@@ -70,7 +71,8 @@ int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const floa
                      int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, float eps, void* stream);
 int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                      const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
-                     int64_t lddx, float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream);
+                     int64_t lddx, float* dgamma, float* dbeta, float* dxsum /* += column sums of dx, or NULL */, int32_t M, int32_t D,
+                     void* stream);
 
 /* ------------------------------------------------------------------ fused attention (head_dim 64, N <= 256)
  * Replaces models/mae.py:130-138 (reshape/permute, q k^T * scale, softmax, attn v, transpose/reshape).

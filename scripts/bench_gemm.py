@@ -14,6 +14,8 @@ for name, N, K in [("qkv", 3 * d, d), ("proj", d, d), ("fc1", 4 * d, d), ("fc2",
     cases.append((f"dgrad NN {name}", dict(A=rb(M, N), B=rb(N, K), a_kmajor=True, b_kmajor=False, out_bf16=torch.empty(M, K, device=dev, dtype=torch.bfloat16)), 2.0 * M * N * K))
     out = torch.zeros(N, K, device=dev)
     cases.append((f"wgrad TN {name}", dict(A=rb(M, N), B=rb(M, K), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=ops.pick_split_k(N, K, M)), 2.0 * M * N * K))
+    cases.append((f"wgrad256 {name}", dict(A=cases[-1][1]["A"], B=cases[-1][1]["B"], a_kmajor=False, b_kmajor=False, out_f32=out,
+                                          split_k=ops.pick_split_k(N, K, M, tile=256), tile256=True), 2.0 * M * N * K))
 def run(kw):
     kw = dict(kw); A = kw.pop("A"); B = kw.pop("B")
     ops.gemm(A, B, **kw)

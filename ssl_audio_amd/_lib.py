@@ -27,7 +27,7 @@ class SaGemmArgs(C.Structure):
         ("residual", P), ("ldr", I64), ("res_mod", I32),
         ("out_f32", P), ("ldo_f32", I64),
         ("out_bf16", P), ("ldo_bf16", I64),
-        ("row_group", I32), ("split_k", I32), ("accumulate", I32),
+        ("row_group", I32), ("split_k", I32), ("accumulate", I32), ("tile256", I32),
     ]
 
 
@@ -38,7 +38,7 @@ _SIGNATURES = {
     "sa_cast_f32_to_bf16": [P, P, I64, P],
     "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P],
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
-    "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, I32, I32, P],
+    "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, I32, I32, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -34,6 +34,7 @@ struct GemmParams {
   int row_group;
   int split_k; int accumulate;
   int tiles_m, tiles_n;
+  int gm;   // row-panels per tile group (L2 locality knob)
 };
 
 // 16-byte-chunk XOR for a k-strided tile row: rows {0..3, 8..11} (one 32-lane half of a transposing
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   const int ntiles = p.tiles_m * p.tiles_n;
   const int ks_id = lid / ntiles;
   const int tile = lid - ks_id * ntiles;
-  constexpr int GM = 8;
+  const int GM = p.gm;
   const int group_sz = GM * p.tiles_n;
   const int grp = tile / group_sz, within = tile - grp * group_sz;
   const int gm = min(GM, p.tiles_m - grp * GM);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
 // the same code.  Per K-tile the wave walks four C-quadrants (A-half0 x B-half0, A0 x B1, A1 x B1, A1 x B0) so only
 // 12 fragment registers sets are live; the next K-tile's 4 half-tiles are requested at the top of the iteration and
 // awaited at its end (one barrier per K-tile).
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A half0 | A half1 | B half0 | B half1]
   constexpr int BUF = 4 * TILE_BYTES;
@@ -377,13 +378,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   constexpr int GM = 4;                          // 32 blocks per XCD ~ 4 x 8 tiles in flight
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int ks_id = SPLIT ? lid / ntiles : 0;    // split-K slice slowest (co-resident workgroups share their K rows in L2)
+  const int tile = lid - ks_id * ntiles;
   const int group_sz = GM * p.tiles_n;
-  const int grp = lid / group_sz, within = lid - grp * group_sz;
+  const int grp = tile / group_sz, within = tile - grp * group_sz;
   const int gm = min(GM, p.tiles_m - grp * GM);
   const int tm = grp * GM + within % gm, tn = within / gm;
   const int m0 = tm * 256, n0 = tn * 256;
 
-  const int ksteps = (p.K + BK - 1) / BK;
+  const int ksteps_all = (p.K + BK - 1) / BK;
+  const int chunk = (ksteps_all + p.split_k - 1) / p.split_k;
+  const int kt0 = SPLIT ? ks_id * chunk : 0;
+  const int ksteps = SPLIT ? min(ksteps_all - kt0, chunk) : ksteps_all;
+  if (ksteps <= 0) return;
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
 
@@ -400,13 +408,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
   };
 
-  stage_all(smem, 0);
+  stage_all(smem, kt0 * BK);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
   for (int kt = 0; kt < ksteps; ++kt) {
-    if (kt + 1 < ksteps) stage_all(smem + (cur ^ 1) * BUF, (kt + 1) * BK);
+    if (kt + 1 < ksteps) stage_all(smem + (cur ^ 1) * BUF, (kt0 + kt + 1) * BK);
     const char* ta = smem + cur * BUF + wr * TILE_BYTES;                 // this wave's A half-tile (128 rows)
     const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;    // this wave's B half-tile
     const int bcol = (wc & 1) * 64;
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb0[j][ks], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0));
     // quadrant (0,1)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][2 + j] = (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb1[j][ks], acc[i][2 + j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0));
     // quadrant (1,1)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -447,21 +455,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb1[j][ks], acc[4 + i][2 + j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0));
     // quadrant (1,0)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[4 + i][j] = (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb0[j][ks], acc[4 + i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---------------------------------------------------------------- epilogue (lane: one row m, 4 consecutive n)
   const int g = lane >> 4, c = lane & 15;
+  if constexpr (SPLIT) {
+    // split-K: lane owns rows 4g + r of one column -> 64-byte row segments per atomic instruction
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wr * 128 + i * 16 + 4 * g + r;
+          if (m < p.M && n < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+        }
+      }
+    return;
+  }
+  // ---------------------------------------------------------------- epilogue (lane: one row m, 4 consecutive n)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + c;
@@ -527,17 +550,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   }
 }
 
-template <bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM, bool SPLIT = false>
 int launch256(GemmParams p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KM, B_KM, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               8 * TILE_BYTES);
     configured = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM>), dim3(p.tiles_m * p.tiles_n), dim3(512), 8 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_kernel<A_KM, B_KM, SPLIT>), dim3(p.tiles_m * p.tiles_n * (SPLIT ? p.split_k : 1)), dim3(512), 8 * TILE_BYTES,
+                     stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256)");
   return 0;
 }
@@ -1001,6 +1025,9 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
+  static const char* gm_env = getenv("SA_GEMM_GM");
+  p.gm = gm_env ? atoi(gm_env) : 8;
+  if (p.gm < 1) p.gm = 1;
 
   // large dense problems go to the 256 x 256 kernel (half the operand bytes per FLOP through the CU's L2 path)
   static const char* force = getenv("SA_GEMM_TILE");
@@ -1034,6 +1061,13 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
     if (a->a_kmajor && !a->b_kmajor) return launch256<true, false>(p, stream);
     if (!a->a_kmajor && a->b_kmajor) return launch256<false, true>(p, stream);
     return launch256<false, false>(p, stream);
+  }
+  if (a->split_k > 1 && a->tile256) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch256<true, true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256<true, false, true>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256<false, true, true>(p, stream);
+    return launch256<false, false, true>(p, stream);
   }
   const bool swap = a->split_k == 1;
   const int sel = (a->a_kmajor ? 4 : 0) | (a->b_kmajor ? 2 : 0) | (swap ? 1 : 0);

@@ -72,13 +72,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
                                                      float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                     int M, int D) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
-  float4 ag[MAXV], ab[MAXV];
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ag[MAXV], ab[MAXV], ax[MAXV];   // column partials: dgamma, dbeta, and sum of the OUTPUT dx (= bias gradient of the
+#pragma unroll                           // Linear whose output gradient dx is: proj for LN2, the previous block's fc2 for LN1)
+  for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mean = mean_in[row], rstd = rstd_in[row];
@@ -125,10 +126,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
           bf16x4 h = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
           reinterpret_cast<bf16x4*>(dx_bf16 + (int64_t)row * lddx)[c] = h;
         }
+        ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
       }
     }
   }
-  if (dgamma == nullptr && dbeta == nullptr) return;
+  if (dgamma == nullptr && dbeta == nullptr && dxsum == nullptr) return;
   // cross-wave reduce of the per-lane column partials, then one atomic per column per block
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
@@ -158,6 +160,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
       atomicAdd(dbeta + 4 * c + 0, t.x); atomicAdd(dbeta + 4 * c + 1, t.y);
       atomicAdd(dbeta + 4 * c + 2, t.z); atomicAdd(dbeta + 4 * c + 3, t.w);
     }
+    if (dxsum) {
+      __syncthreads();
+      reinterpret_cast<float4*>(red)[wave * 64 + lane] = ax[i];
+      __syncthreads();
+      if (wave == 0 && c < nv) {
+        float4 t = reinterpret_cast<float4*>(red)[lane];
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        atomicAdd(dxsum + 4 * c + 0, t.x); atomicAdd(dxsum + 4 * c + 1, t.y);
+        atomicAdd(dxsum + 4 * c + 2, t.z); atomicAdd(dxsum + 4 * c + 3, t.w);
+      }
+    }
   }
 }
 
@@ -184,7 +200,7 @@ extern "C" int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma,
 
 extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
-                                int64_t lddx, float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
+                                int64_t lddx, float* dgamma, float* dbeta, float* dxsum, int32_t M, int32_t D, void* stream) {
   SA_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "sa_layernorm_bwd: null pointer");
   SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV_LIMIT, "sa_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV_LIMIT);
   SA_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "sa_layernorm_bwd: leading dims must be multiples of 4");
@@ -193,7 +209,7 @@ extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy
   if (grid > 1024) grid = 1024;
   const int nv = (D / 4 + 63) / 64;
 #define SA_LN_BWD(T, V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy, x, ldx, \
-                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, M, D)
+                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, dxsum, M, D)
 #define SA_LN_BWD_V(T) do { if (nv <= 1) SA_LN_BWD(T, 1); else if (nv == 2) SA_LN_BWD(T, 2); else if (nv == 3) SA_LN_BWD(T, 3); \
                             else if (nv == 4) SA_LN_BWD(T, 4); else SA_LN_BWD(T, 8); } while (0)
   if (dy_is_bf16) SA_LN_BWD_V(bf16_t); else SA_LN_BWD_V(float);

@@ -77,7 +77,15 @@ def grad_target(p):
 def _wgrad(dY16, X16, out):
     """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip)."""
     N, K = out.shape
-    split = ops.pick_split_k(N, K, dY16.shape[0])
+    rows = dY16.shape[0]
+    # measured (scripts/bench_gemm.py): with >= 16 output tiles of 256 x 256 the one-workgroup-per-CU 256^2 split-K tile wins
+    # (halved operand traffic, the long reduction hides its epilogue); narrower outputs stay on the 128^2 tile
+    if ((N + 255) // 256) * ((K + 255) // 256) >= 16 and rows >= 4096:
+        split = ops.pick_split_k(N, K, rows, tile=256)
+        if split > 1:
+            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=True)
+            return
+    split = ops.pick_split_k(N, K, rows)
     if split > 1:
         ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split)
     else:
@@ -125,16 +133,20 @@ def block_forward(x, p, H, N, eps, save):
     return x3
 
 
-def block_backward(dx3, dx3_16, p, g, H, N, saved):
+def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     """dx3 fp32 / dx3_16 bf16: gradient of the block output.  g: BlockParams of fp32 gradient buffers (accumulated
-    into).  Returns (dx fp32, dx bf16) w.r.t. the block input."""
+    into).  Returns (dx fp32, dx bf16) w.r.t. the block input.
+    Bias gradients that are column sums of a LayerNorm-backward OUTPUT are accumulated inside that kernel: proj's bias
+    from LN2's dx, and the PREVIOUS block's fc2 bias (`prev_b2`) from LN1's dx; `b2_done` says the later block already
+    did that for this block's fc2 bias."""
     x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a = saved
     M, d = x.shape
     dev = x.device
     W = BF16_WEIGHTS.get
     # fc2
     _wgrad(dx3_16, a, g.w2)
-    ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
+    if not b2_done:
+        ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
     ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre)   # (dY W2) * GELU'(pre)
     # fc1
@@ -146,10 +158,9 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved):
     # LN2 + residual
     dx2 = torch.empty(M, d, device=dev)
     dx2_16 = torch.empty(M, d, dtype=BF16, device=dev)
-    ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_f32=dx2, dx_bf16=dx2_16, dgamma=g.n2w, dbeta=g.n2b)
+    ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_f32=dx2, dx_bf16=dx2_16, dgamma=g.n2w, dbeta=g.n2b, dxsum=g.bp)
     # proj
     _wgrad(dx2_16, ao, g.wp)
-    ops.colsum_bf16(dx2_16, g.bp, accumulate=True)
     dao = dh2  # reuse
     ops.gemm(dx2_16, W(p.wp), b_kmajor=False, out_bf16=dao)
     # attention
@@ -165,7 +176,7 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved):
     # LN1 + residual
     dx = torch.empty(M, d, device=dev)
     dx_16 = dx2_16
-    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b)
+    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b, dxsum=prev_b2)
     return dx, dx_16
 
 
@@ -204,7 +215,7 @@ def block_forward_cls(x, p, H, N, eps, save):
     return x3
 
 
-def block_backward_cls(dx3, dx3_16, p, g, H, N, saved):
+def block_backward_cls(dx3, dx3_16, p, g, H, N, saved, prev_b2=None):
     """Backward of block_forward_cls: dx3 / dx3_16 are the [S, d] gradients of the CLS output rows."""
     x, mean1, rstd1, h1, qkv, ao, lse, x2, mean2, rstd2, h2, pre, a = saved
     M, d = x.shape
@@ -239,7 +250,7 @@ def block_backward_cls(dx3, dx3_16, p, g, H, N, saved):
     del dqkv
     dx = torch.empty(M, d, device=dev)
     dx_16 = torch.empty(M, d, dtype=BF16, device=dev)
-    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b)
+    ops.layernorm_bwd(dh1, x, p.n1w, mean1, rstd1, dres=dx2, dx_f32=dx, dx_bf16=dx_16, dgamma=g.n1w, dbeta=g.n1b, dxsum=prev_b2)
     return dx, dx_16
 
 
@@ -318,10 +329,11 @@ class EncoderFn(torch.autograd.Function):
         for i in reversed(range(n_blocks)):
             bp = BlockParams(params[13 * i:13 * (i + 1)])
             bg = BlockParams(gz[13 * i:13 * (i + 1)])
+            prev_b2 = gz[13 * (i - 1) + 12] if i > 0 else None          # fc2 bias gradient buffer of block i-1
             if cls_prune and i == n_blocks - 1:
-                dx, dx16 = block_backward_cls(dx, dx16, bp, bg, H, N, ctx.saved[i])
+                dx, dx16 = block_backward_cls(dx, dx16, bp, bg, H, N, ctx.saved[i], prev_b2=prev_b2)
             else:
-                dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i])
+                dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i], b2_done=(i < n_blocks - 1), prev_b2=prev_b2)
             ctx.saved[i] = None
             if BLOCK_DONE_HOOK is not None:
                 BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])

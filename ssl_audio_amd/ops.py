@@ -40,7 +40,7 @@ def _rows(t, name):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False):
+         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False, tile256=False):
     """D = epilogue(alpha * A.B).  A: [M,K] (a_kmajor) or [K,M]; B: [N,K] (b_kmajor, nn.Linear weight) or [K,N]."""
     _req(A, BF16, "A"), _req(B, BF16, "B")
     ar, ac, lda = _rows(A, "A")
@@ -66,7 +66,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
         a.out_f32, a.ldo_f32 = _req(out_f32, F32, "out_f32").data_ptr(), _rows(out_f32, "out_f32")[2]
     if out_bf16 is not None:
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
-    a.row_group, a.split_k, a.accumulate = row_group, split_k, int(accumulate)
+    a.row_group, a.split_k, a.accumulate, a.tile256 = row_group, split_k, int(accumulate), int(tile256)
     if GEMM_PROFILE is None:
         check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
         return
@@ -81,11 +81,11 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes))
 
 
-def pick_split_k(M, N, K, cu_count=256):
+def pick_split_k(M, N, K, cu_count=256, tile=128):
     """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     ksteps = (K + 63) // 64
-    slots = 2 * cu_count                   # the 128^2 kernel runs two workgroups per CU
+    slots = (2 if tile == 128 else 1) * cu_count       # the 128^2 kernel runs two workgroups per CU, the 256^2 one
     if tiles >= slots or ksteps < 16:
         return 1
     # time ~ (rounds of resident workgroups) x (K-iterations per workgroup + fill/epilogue): a split that leaves the last
@@ -125,14 +125,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rs
                                  _stream()), "sa_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None, dxsum=None):
     M, D, ldx = _rows(_req(x, F32, "x"), "x")
     lddy = _rows(dy, "dy")[2]
     dxo = dx_f32 if dx_f32 is not None else dx_bf16
     lddx = _rows(dxo, "dx")[2]
     lddres = _rows(dres, "dres")[2] if dres is not None else 0
     check(lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
-                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), M, D, _stream()), "sa_layernorm_bwd")
+                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), M, D, _stream()), "sa_layernorm_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ attention

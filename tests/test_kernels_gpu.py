@@ -100,6 +100,12 @@ def test_gemm_split_k_wgrad(dev):
     ops.gemm(dY.to(dev), X.to(dev), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split)
     assert rel_err(out, ref) < 1e-5
     assert ops.pick_split_k(768, 768, 63744) >= 8
+    # the 256 x 256 split-K tile (one workgroup per CU) on ragged output and reduction sizes
+    Mtok, N, K = 3000, 320, 520
+    dY = bf(rnd((Mtok, N), 81)); X = bf(rnd((Mtok, K), 82))
+    out = torch.zeros(N, K, device=dev)
+    ops.gemm(dY.to(dev), X.to(dev), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=5, tile256=True, alpha=0.5)
+    assert rel_err(out, 0.5 * (dY.double().T @ X.double())) < 1e-5
 
 
 def test_cast_and_colsum(dev):
@@ -127,8 +133,10 @@ def test_layernorm(dev, M, D):
     ref.backward(dy.double())
     dx = torch.empty(M, D, device=dev); dx16 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
     dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
-    ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres=dres.to(dev), dx_f32=dx, dx_bf16=dx16, dgamma=dg, dbeta=db)
+    dxs = torch.zeros(D, device=dev)
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, dres=dres.to(dev), dx_f32=dx, dx_bf16=dx16, dgamma=dg, dbeta=db, dxsum=dxs)
     assert rel_err(dx, xd.grad + dres.double()) < 5e-6
+    assert rel_err(dxs, (xd.grad + dres.double()).sum(0)) < 1e-5        # fused bias-gradient column sum of the output
     assert rel_err(dx16, xd.grad + dres.double()) < 4e-3
     assert rel_err(dg, gd.grad) < 1e-5 and rel_err(db, bd.grad) < 1e-5
     # bf16 upstream gradient path (what the dgrad GEMMs hand over)
