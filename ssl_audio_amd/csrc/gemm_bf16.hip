@@ -911,6 +911,150 @@ int launch_persist(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
+// =====================================================================================================
+// Persistent 256 x 256 x 64 kernel (forward / dgrad): one workgroup per CU walks tiles lid, lid + grid, ...  With a single
+// resident workgroup nothing else hides the pipeline fill and the store tail of a 12-iteration (K = 768) tile, so the
+// kernel hides them itself: the next tile's first K-tile is requested during the last K-iteration and lands while the
+// epilogue runs, and the epilogue stages through the 64 KiB pipeline stage that was just consumed (8 KiB per wave, two
+// 64-row passes).
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
+  constexpr int BUF = 4 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  auto coords = [&](int t, int& m0, int& n0) {
+    const int grp = t / group_sz, within = t - grp * group_sz;
+    const int gm = min(GM, p.tiles_m - grp * GM);
+    m0 = (grp * GM + within % gm) * 256;
+    n0 = (within / gm) * 256;
+  };
+  const int ksteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+  auto stage_all = [&](char* buf, int m0, int n0, int k0) {
+    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
+    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+  };
+
+  int t = lid;
+  if (t >= ntiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+  stage_all(smem, m0, n0, 0);
+  int cur = 0;
+  while (true) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int tnext = t + nwg;
+    const bool has_next = tnext < ntiles;
+    int m0n = 0, n0n = 0;
+    if (has_next) coords(tnext, m0n, n0n);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ksteps; ++kt) {
+      const bool more = kt + 1 < ksteps;
+      if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
+      else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
+      const char* ta = smem + cur * BUF + wr * TILE_BYTES;
+      const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
+      const int bcol = (wc & 1) * 64;
+      bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // raw: the next tile's LDS-DMA stays in flight
+    char* wl = smem + cur * BUF + wave * 8192;
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    if (!has_next) break;
+    t = tnext; m0 = m0n; n0 = n0n;
+    cur ^= 1;
+  }
+}
+
+template <bool A_KM, bool B_KM>
+int launch256_persist(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: cannot query the device");
+      return 2;
+    }
+    slots = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              8 * TILE_BYTES);
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
+  return 0;
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 int launch(const GemmParams& p, hipStream_t stream) {
   const int nwg = p.tiles_m * p.tiles_n * p.split_k;
@@ -1035,8 +1179,16 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   // Measured on the ViT-B shapes (scripts/bench_gemm.py, random operands): the 128^2 kernel (mode 1, two 4-wave
   // workgroups per CU) beats the 192x128 (mode 4), 256x128 three-stage (mode 3) and 256^2 (mode 2) variants at K = 768;
   // those stay selectable through SA_GEMM_TILE for experiments and are parity-tested.
-  const char mode = force ? force[0] : '1';   // (mode 5, persistent, measured equal to mode 1: 3.51 vs 3.46 ms per layer)
-  (void)big;
+  // default for large problems: mode 6, the persistent 256 x 256 kernel (measured 12 % faster than mode 1 over the ViT-B
+  // forward + dgrad shapes: scripts/bench_gemm.py); small / ragged problems use the plain 128 x 128 kernel.
+  const char mode = force ? force[0] : (big ? '6' : '1');
+  if (mode == '6' && a->split_k == 1) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch256_persist<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256_persist<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256_persist<false, true>(p, stream);
+    return launch256_persist<false, false>(p, stream);
+  }
   if (mode == '5' && a->split_k == 1) {
     if (a->a_kmajor && a->b_kmajor) return launch_persist<true, true>(p, stream);
     if (a->a_kmajor && !a->b_kmajor) return launch_persist<true, false>(p, stream);
