@@ -18,7 +18,7 @@ namespace {
 constexpr int HD = 64;          // head dim
 constexpr int NMAX = 256;       // max tokens per sequence
 constexpr int IMG = NMAX * HD * 2;  // bytes of one [256][64] bf16 LDS image
-constexpr int NW_FWD = 4;           // waves per workgroup, forward
+constexpr int NW_FWD = 8;           // waves per workgroup, forward (64 KiB of LDS -> two workgroups = 16 waves per CU)
 constexpr int NW_BWD = 8;           // backward: 8 waves per workgroup, two workgroups per CU (66 KiB of LDS each)
 
 // ---- LDS image: [rows][64] bf16, 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7)
@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 #define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
 
 // =====================================================================================================
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+__global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kimg = smem;
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
 
   const int g = lane >> 4, c = lane & 15;
   const int nqt = (nq + 15) >> 4;            // only the first nq queries of each sequence are wanted (nq = N normally)
+  f32x4 kbias;                               // accumulator start of the last key tile: -inf on keys >= N, else 0
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kbias[r] = ((nkt - 1) * 16 + 4 * g + r >= N) ? -INFINITY : 0.f;
   for (int qt = wave; qt < nqt; qt += NW_FWD) {
     // Q fragments for this lane's query (Y operand: k = d)
     const int query = qt * 16 + c;
@@ -107,30 +110,30 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
     // S^T tiles: st[kt][r] = score(key = 16*kt + 4*g + r, query)
     f32x4 st[16];
     float mx = -INFINITY;
+    f32x4 kb = kbias;                                  // opaque copy: keeps the 16 per-tile selects below from being hoisted
+    asm volatile("" : "+v"(kb));                       // out of the query-tile loop (64 live VGPRs -> spills)
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {
+        if (kt == nkt - 1) st[kt] = kb;                // padding keys start at -inf: the MFMA accumulate keeps them there
         st[kt] = MFMA16(row_frag(Kimg, kt * 16, 0, lane), qf[0], st[kt]);
         st[kt] = MFMA16(row_frag(Kimg, kt * 16, 1, lane), qf[1], st[kt]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const float v = key < N ? st[kt][r] * scale : -INFINITY;
-          st[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);   // raw scores; the (positive) scale is folded into the exponent
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
+    const float c2 = scale * 1.44269504088896340736f;            // exp(scale * (s - max)) = exp2(c2 * s - c2 * max): one fma + v_exp
+    const float mb = mx * c2;
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt) {
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(st[kt][r] - mx);  // exp(-inf) = 0 for masked keys
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c2, -mb));   // exp2(-inf) = 0 for masked keys
           st[kt][r] = p;
           sum += p;
         }
@@ -158,13 +161,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
         bf16x4 o = {f2bf(ot[dt][0] * inv), f2bf(ot[dt][1] * inv), f2bf(ot[dt][2] * inv), f2bf(ot[dt][3] * inv)};
         *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = o;
       }
-      if (g == 0 && lse) lse[((int64_t)s * H + h) * N + query] = mx + __logf(sum);
+      if (g == 0 && lse) lse[((int64_t)s * H + h) * N + query] = mx * scale + __logf(sum);
     }
   }
 }
 
 // =====================================================================================================
-__global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+__global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
   // delta[q] = sum_d dO[q][d] * O[q][d]  (straight from global, one query row per thread), lse -> LDS
   {
     const int q = threadIdx.x;
-    float dl = 0.f, ls = 0.f;
+    float dl = 0.f, ls = INFINITY;                   // queries >= nq: lse = +inf makes every p exactly 0
     if (q < nq && q < NMAX) {
       const bf16x8* po = reinterpret_cast<const bf16x8*>(o + (row_base + q) * ldo + h * HD);
       const bf16x8* pd = reinterpret_cast<const bf16x8*>(dout + (row_base + q) * ldo + h * HD);
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
         for (int j = 0; j < 8; ++j) dl += bf2f(a[j]) * bf2f(b[j]);
       }
-      ls = lse[((int64_t)s * H + h) * N + q];
+      ls = lse[((int64_t)s * H + h) * N + q] * 1.44269504088896340736f;   // kept in log2 units for v_exp
     }
     if (q < NMAX) {
       del_s[q] = dl;
@@ -212,6 +215,25 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
   __syncthreads();
 
   const int g = lane >> 4, c = lane & 15;
+  // per-lane LDS offsets, loop invariant: tile bases are multiples of 16 rows, so (row & 7) never depends on the tile
+  const int rf0 = c * 128 + ((g ^ (c & 7)) << 4), rf1 = c * 128 + (((4 + g) ^ (c & 7)) << 4);       // row_frag, k-step 0 / 1
+  int trf[4];                                                                                        // tr_frag, d-tile 0..3
+  {
+    const int rr0 = 4 * g + (c >> 2), pp = c & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) trf[dt] = rr0 * 128 + ((((dt * 2) + (pp >> 1)) ^ (rr0 & 7)) << 4) + (pp & 1) * 8;
+  }
+  auto RF = [&](const char* img, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(img + tile * 2048 + (ks ? rf1 : rf0)); };
+  auto TR = [&](const char* img, int step, int dt) {
+    const char* b = img + step * 4096 + trf[dt];
+    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
+    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 2048));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  const float c2 = scale * 1.44269504088896340736f;    // p = exp(scale*s - lse) = exp2(c2*s - lse*log2e)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
   const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
@@ -229,7 +251,6 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
     const bf16x8 qf0 = row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), qf1 = row_frag_global(rs, ld, qt * 16, h * HD, 1, lane);
     const bf16x8 df0 = row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), df1 = row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane);
     const float lq = lse_s[query], dq_delta = del_s[query];
-    const bool qvalid = query < nq;
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -238,27 +259,30 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int kt = 2 * ps + u;
-        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-        sv = MFMA16(row_frag(Kimg, kt * 16, 0, lane), qf0, sv);
-        sv = MFMA16(row_frag(Kimg, kt * 16, 1, lane), qf1, sv);
-        dp = MFMA16(row_frag(Vimg, kt * 16, 0, lane), df0, dp);
-        dp = MFMA16(row_frag(Vimg, kt * 16, 1, lane), df1, dp);
+        f32x4 sv = zero4, dp = zero4;
+        if (kt >= nkt - 1) {                            // wave-uniform and rare: tiles holding keys >= N start at -inf
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : 0.f;
+        }
+        sv = MFMA16(RF(Kimg, kt, 0), qf0, sv);
+        sv = MFMA16(RF(Kimg, kt, 1), qf1, sv);
+        dp = MFMA16(RF(Vimg, kt, 0), df0, dp);
+        dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const float p = (qvalid && key < N) ? __expf(sv[r] * scale - lq) : 0.f;
-          ds[u][r] = p * (dp[r] - dq_delta) * scale;
+          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
+          ds[u][r] = p * (dp[r] - dq_delta);                              // the softmax scale is applied once, to the accumulator
         }
       }
       const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(tr_frag(Kimg, 32 * ps, 32 * ps + 16, dt * 16, lane), dsf, acc[dt]);
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(TR(Kimg, ps, dt), dsf, acc[dt]);
     }
     if (query < N) {
       bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 v = {f2bf(acc[dt][0]), f2bf(acc[dt][1]), f2bf(acc[dt][2]), f2bf(acc[dt][3])};
+        bf16x4 v = {f2bf(acc[dt][0] * scale), f2bf(acc[dt][1] * scale), f2bf(acc[dt][2] * scale), f2bf(acc[dt][3] * scale)};
         *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
       }
     }
@@ -273,6 +297,8 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
   for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
+    const float kb = kvalid ? 0.f : -INFINITY;
+    const f32x4 kb4 = {kb, kb, kb, kb};
     const bf16x8 kf0 = row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), kf1 = row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane);
     const bf16x8 vf0 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), vf1 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane);
     f32x4 dk[4], dv[4];
@@ -283,24 +309,26 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qs + u;
-        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-        sv = MFMA16(row_frag(Qimg, qt * 16, 0, lane), kf0, sv);   // D[query = 4g + r][key = c]
-        sv = MFMA16(row_frag(Qimg, qt * 16, 1, lane), kf1, sv);
-        dp = MFMA16(row_frag(Dimg, qt * 16, 0, lane), vf0, dp);
-        dp = MFMA16(row_frag(Dimg, qt * 16, 1, lane), vf1, dp);
+        f32x4 sv = kb4, dp = zero4;
+        sv = MFMA16(RF(Qimg, qt, 0), kf0, sv);   // D[query = 4g + r][key = c]
+        sv = MFMA16(RF(Qimg, qt, 1), kf1, sv);
+        dp = MFMA16(RF(Dimg, qt, 0), vf0, dp);
+        dp = MFMA16(RF(Dimg, qt, 1), vf1, dp);
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + 4 * g);      // this lane's 4 queries
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qt * 16 + 4 * g);
+        const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int query = qt * 16 + 4 * g + r;
-          const float p = (kvalid && query < nq) ? __expf(sv[r] * scale - lse_s[query]) : 0.f;
+          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r]));
           pp[u][r] = p;
-          ds[u][r] = p * (dp[r] - del_s[query]) * scale;
+          ds[u][r] = p * (dp[r] - dq4[r]);
         }
       }
       const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = MFMA16(tr_frag(Dimg, 32 * qs, 32 * qs + 16, dt * 16, lane), pf, dv[dt]);    // dV^T[d][key]
-        dk[dt] = MFMA16(tr_frag(Qimg, 32 * qs, 32 * qs + 16, dt * 16, lane), dsf, dk[dt]);   // dK^T[d][key]
+        dv[dt] = MFMA16(TR(Dimg, qs, dt), pf, dv[dt]);    // dV^T[d][key]
+        dk[dt] = MFMA16(TR(Qimg, qs, dt), dsf, dk[dt]);   // dK^T[d][key]
       }
     }
     if (kvalid) {
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 2) void attn_bwd_kernel(const bf16_t* 
       bf16_t* vrow = krow + C;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 a = {f2bf(dk[dt][0]), f2bf(dk[dt][1]), f2bf(dk[dt][2]), f2bf(dk[dt][3])};
+        bf16x4 a = {f2bf(dk[dt][0] * scale), f2bf(dk[dt][1] * scale), f2bf(dk[dt][2] * scale), f2bf(dk[dt][3] * scale)};
         bf16x4 b = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
         *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
         *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = b;
@@ -340,7 +368,7 @@ extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32
     configured = true;
   }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(256), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(64 * NW_FWD), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
                      scale, (bf16_t*)out, (int)ldo, lse);
   SA_LAUNCH_CHECK("sa_attention_fwd");
   return 0;
