@@ -66,13 +66,16 @@ int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, 
 
 /* ------------------------------------------------------------------ LayerNorm (fp32 stream -> bf16/fp32)
  * Replaces nn.LayerNorm(eps=1e-6) at models/mae.py:149,153,208,227 (fwd + bwd).  One wave per row, D <= 2048.
- * bwd: dx = dres + LN'(dy); dgamma/dbeta are ATOMICALLY ADDED into (caller zeroes or accumulates). */
+ * bwd: dx = dres + LN'(dy); dgamma/dbeta/dxsum are ADDED into (caller zeroes or accumulates) by a deterministic
+ * two-stage reduction through `workspace` (sa_layernorm_bwd_workspace_bytes(M, D) bytes, required iff any of the three
+ * is non-NULL; contents are scratch). */
 int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                      int64_t ldy, float* mean, float* rstd, int32_t M, int32_t D, float eps, void* stream);
 int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                      const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
-                     int64_t lddx, float* dgamma, float* dbeta, float* dxsum /* += column sums of dx, or NULL */, int32_t M, int32_t D,
-                     void* stream);
+                     int64_t lddx, float* dgamma, float* dbeta, float* dxsum /* += column sums of dx, or NULL */, float* workspace,
+                     int32_t M, int32_t D, void* stream);
+int64_t sa_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
 
 /* ------------------------------------------------------------------ fused attention (head_dim 64, N <= 256)
  * Replaces models/mae.py:130-138 (reshape/permute, q k^T * scale, softmax, attn v, transpose/reshape).

@@ -38,7 +38,8 @@ _SIGNATURES = {
     "sa_cast_f32_to_bf16": [P, P, I64, P],
     "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P],
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
-    "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, I32, I32, P],
+    "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
+    "sa_layernorm_bwd_workspace_bytes": [I32, I32],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],
@@ -67,7 +68,7 @@ def header_symbols():
     with open(HEADER_PATH) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(sa_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(sa_\w+)\s*\(", text)))
 
 
 class HipLibraryMissing(RuntimeError):
@@ -93,7 +94,7 @@ def lib():
         if name == "sa_last_error":
             continue
         fn = getattr(h, name)  # AttributeError here = header/library mismatch, let it surface
-        fn.restype = I32
+        fn.restype = I64 if name.endswith("_bytes") else I32
         sig = _SIGNATURES.get(name)
         if sig is not None:
             fn.argtypes = sig

@@ -66,14 +66,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy
 // dy arrives as bf16 (from a dgrad GEMM) or fp32 (from the loss side).  Each lane owns fixed columns, so its
-// dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + atomics at the end.
+// dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + a workspace row at the end.
 template <typename DY, int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
                                                      float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
-                                                     int M, int D) {
+                                                     float* __restrict__ ws, int M, int D) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -130,39 +129,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
       }
     }
   }
-  if (dgamma == nullptr && dbeta == nullptr && dxsum == nullptr) return;
-  // cross-wave reduce of the per-lane column partials, then one atomic per column per block
+  if (ws == nullptr) return;
+  // Column partials leave the block through a workspace ([kind][block][D]); ln_bwd_reduce_kernel sums them.  (Atomics on
+  // 3*D addresses from ~1000 blocks are resolved memory-side across the 8 XCDs and cost more than the whole streaming pass.)
+  const int nblk = gridDim.x;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
     if (i * 64 >= nv) break;
-    __syncthreads();
-    reinterpret_cast<float4*>(red)[wave * 64 + lane] = ag[i];
-    __syncthreads();
-    if (wave == 0 && c < nv && dgamma) {
-      float4 t = reinterpret_cast<float4*>(red)[lane];
-      for (int w = 1; w < 4; ++w) {
-        const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      atomicAdd(dgamma + 4 * c + 0, t.x); atomicAdd(dgamma + 4 * c + 1, t.y);
-      atomicAdd(dgamma + 4 * c + 2, t.z); atomicAdd(dgamma + 4 * c + 3, t.w);
-    }
-    __syncthreads();
-    reinterpret_cast<float4*>(red)[wave * 64 + lane] = ab[i];
-    __syncthreads();
-    if (wave == 0 && c < nv && dbeta) {
-      float4 t = reinterpret_cast<float4*>(red)[lane];
-      for (int w = 1; w < 4; ++w) {
-        const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      atomicAdd(dbeta + 4 * c + 0, t.x); atomicAdd(dbeta + 4 * c + 1, t.y);
-      atomicAdd(dbeta + 4 * c + 2, t.z); atomicAdd(dbeta + 4 * c + 3, t.w);
-    }
-    if (dxsum) {
+#pragma unroll
+    for (int kind = 0; kind < 3; ++kind) {
       __syncthreads();
-      reinterpret_cast<float4*>(red)[wave * 64 + lane] = ax[i];
+      reinterpret_cast<float4*>(red)[wave * 64 + lane] = kind == 0 ? ag[i] : kind == 1 ? ab[i] : ax[i];
       __syncthreads();
       if (wave == 0 && c < nv) {
         float4 t = reinterpret_cast<float4*>(red)[lane];
@@ -170,11 +148,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
           const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
           t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        atomicAdd(dxsum + 4 * c + 0, t.x); atomicAdd(dxsum + 4 * c + 1, t.y);
-        atomicAdd(dxsum + 4 * c + 2, t.z); atomicAdd(dxsum + 4 * c + 3, t.w);
+        reinterpret_cast<float4*>(ws + ((int64_t)kind * nblk + blockIdx.x) * D)[c] = t;
       }
     }
   }
+}
+
+// out[kind][col] += sum over blocks of ws[kind][block][col]; 16 waves split the blocks, lanes are columns
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dxsum) {
+  __shared__ float red[16][64];
+  const int kind = blockIdx.y;
+  float* out = kind == 0 ? dgamma : kind == 1 ? dbeta : dxsum;
+  if (out == nullptr) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const float* base = ws + (int64_t)kind * nblk * D + col;
+  float acc = 0.f;
+  if (col < D) {
+    int p = wave;
+    for (; p + 7 * 16 < nblk; p += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(p + u * 16) * D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; p < nblk; p += 16) acc += base[(int64_t)p * D];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    out[col] += t;
+  }
+}
+
+inline int ln_bwd_grid(int M) {   // fewer, fatter blocks than forward: every block ends with a 3*D partial
+  const int g = (M + 3) / 4;
+  return g > 1024 ? 1024 : g;
 }
 
 inline int ln_grid(int M) {
@@ -198,23 +212,32 @@ extern "C" int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma,
   return 0;
 }
 
+extern "C" int64_t sa_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
+  return (int64_t)3 * ln_bwd_grid(M) * D * (int64_t)sizeof(float);
+}
+
 extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, int64_t lddres, float* dx_f32, void* dx_bf16,
-                                int64_t lddx, float* dgamma, float* dbeta, float* dxsum, int32_t M, int32_t D, void* stream) {
+                                int64_t lddx, float* dgamma, float* dbeta, float* dxsum, float* workspace, int32_t M, int32_t D, void* stream) {
   SA_CHECK_ARG(dy && x && gamma && mean && rstd && (dx_f32 || dx_bf16), "sa_layernorm_bwd: null pointer");
   SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV_LIMIT, "sa_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV_LIMIT);
   SA_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "sa_layernorm_bwd: leading dims must be multiples of 4");
-  // fewer, fatter blocks than forward: every block ends with 2*D atomics
-  int grid = (M + 3) / 4;
-  if (grid > 1024) grid = 1024;
+  const bool sums = dgamma || dbeta || dxsum;
+  SA_CHECK_ARG(!sums || workspace, "sa_layernorm_bwd: column sums need a workspace of sa_layernorm_bwd_workspace_bytes(M, D)");
+  const int grid = ln_bwd_grid(M);
+  float* ws = sums ? workspace : nullptr;
   const int nv = (D / 4 + 63) / 64;
 #define SA_LN_BWD(T, V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy, x, ldx, \
-                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, dgamma, dbeta, dxsum, M, D)
+                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, ws, M, D)
 #define SA_LN_BWD_V(T) do { if (nv <= 1) SA_LN_BWD(T, 1); else if (nv == 2) SA_LN_BWD(T, 2); else if (nv == 3) SA_LN_BWD(T, 3); \
                             else if (nv == 4) SA_LN_BWD(T, 4); else SA_LN_BWD(T, 8); } while (0)
   if (dy_is_bf16) SA_LN_BWD_V(bf16_t); else SA_LN_BWD_V(float);
 #undef SA_LN_BWD_V
 #undef SA_LN_BWD
   SA_LAUNCH_CHECK("sa_layernorm_bwd");
+  if (sums) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(1024), 0, (hipStream_t)stream, ws, grid, D, dgamma, dbeta, dxsum);
+    SA_LAUNCH_CHECK("sa_layernorm_bwd(reduce)");
+  }
   return 0;
 }

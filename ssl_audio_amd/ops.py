@@ -131,8 +131,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=N
     dxo = dx_f32 if dx_f32 is not None else dx_bf16
     lddx = _rows(dxo, "dx")[2]
     lddres = _rows(dres, "dres")[2] if dres is not None else 0
+    ws = None
+    if dgamma is not None or dbeta is not None or dxsum is not None:      # scratch for the two-stage column reduction
+        ws = torch.empty(lib().sa_layernorm_bwd_workspace_bytes(M, D) // 4, dtype=F32, device=x.device)
     check(lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
-                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), M, D, _stream()), "sa_layernorm_bwd")
+                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), _p(ws), M, D, _stream()), "sa_layernorm_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ attention
