@@ -58,6 +58,8 @@ typedef struct SaGemmArgs {
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 
+/* diagnostics only: cycle stamps of the persistent 256x256 kernel when SA_GEMM_DBG=8 (2 x 8 counters, see gemm_bf16.hip) */
+int sa_gemm_debug_counters(uint64_t* out16);
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
 int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients); accumulate != 0 adds */

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
     "sa_layernorm_bwd_workspace_bytes": [I32, I32],
+    "sa_gemm_debug_counters": [P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -10,6 +10,7 @@
 // LDS destination of an LDS-DMA is lane-linear, so swizzles are applied to the per-lane SOURCE address
 // and again on the fragment read (cdna_hip_programming.md rule 21).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
 
@@ -67,6 +68,39 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
     }
   }
+}
+
+// one wave-instruction (number q of 16) of stage_tile: lets a kernel space its LDS-DMA requests out between MFMAs
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_one(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane) {
+  uint32_t voff;
+  if constexpr (KMAJOR) {
+    const int row = q * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
+  } else {
+    const int krow = q * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ks_swz(krow);
+    voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
+  }
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+}
+
+// stage_one with a validity flag: an invalid request goes out of range (zero fill, no traffic) so vmcnt bookkeeping stays exact
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_one_v(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane, bool valid) {
+  uint32_t voff;
+  if constexpr (KMAJOR) {
+    const int row = q * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
+  } else {
+    const int krow = q * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ks_swz(krow);
+    voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
+  }
+  voff = valid ? voff : 0xFFFFFFF0u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
 }
 
 // ---- LDS -> register fragment for one 16-wide sub-tile and one 32-deep k-step -------------------------
@@ -917,7 +951,24 @@ int launch_persist(GemmParams p, hipStream_t stream) {
 // kernel hides them itself: the next tile's first K-tile is requested during the last K-iteration and lands while the
 // epilogue runs, and the epilogue stages through the 64 KiB pipeline stage that was just consumed (8 KiB per wave, two
 // 64-row passes).
-template <bool A_KM, bool B_KM>
+// cycle stamps of one wave (DBG bit 3, SA_GEMM_DBG=8): [0] K-steps seen, [1] fragment+MFMA section, [2] vmcnt wait, [3] barrier wait,
+// [4] epilogue, [5] total, [6] tile-top wait.  Read back with sa_gemm_debug_counters().
+__device__ unsigned long long sa_gemm_prof[2][8];
+#define SA_STAMP() ((DBG & 8) ? __builtin_readcyclecounter() : 0ull)
+
+// experiment knob for the persistent kernel (SA_GEMM_DBG): bit 0 = LDS-DMA only on the first K-step, bit 1 = fragment reads
+// only on the first K-step, bit 2 = no MFMA (operands kept alive).  Results are wrong by design; timing isolates a pipe.
+template <int DBG>
+__device__ __forceinline__ f32x4 mfma_dbg(const bf16x8& x, const bf16x8& y, const f32x4& c) {
+  if constexpr (DBG & 4) {
+    asm volatile("" ::"v"(x), "v"(y));
+    return c;
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+  }
+}
+
+template <bool A_KM, bool B_KM, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
   constexpr int BUF = 4 * TILE_BYTES;
@@ -942,10 +993,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
   auto stage_all = [&](char* buf, int m0, int n0, int k0) {
-    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
-    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+    if constexpr (DBG & 32) {          // one wave per SIMD (waves 0..3) issues all the LDS-DMA; its SIMD partner never blocks on the memory pipe
+      if (wave < 4) {
+        stage_tile<A_KM, 4>(ra, buf, p.lda, m0, k0, wave, lane);
+        stage_tile<A_KM, 4>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+        stage_tile<B_KM, 4>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+        stage_tile<B_KM, 4>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+      }
+    } else {
+      stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
+      stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+      stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+      stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+    }
   };
 
   int t = lid;
@@ -954,9 +1014,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   coords(t, m0, n0);
   stage_all(smem, m0, n0, 0);
   int cur = 0;
+  unsigned long long pc_mfma = 0, pc_vm = 0, pc_bar = 0, pc_epi = 0, pc_top = 0, pc_steps = 0;
+  const unsigned long long pc_begin = SA_STAMP();
   while (true) {
+    const unsigned long long tt0 = SA_STAMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    pc_top += SA_STAMP() - tt0;
     const int tnext = t + nwg;
     const bool has_next = tnext < ntiles;
     int m0n = 0, n0n = 0;
@@ -968,68 +1032,112 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
     for (int kt = 0; kt < ksteps; ++kt) {
       const bool more = kt + 1 < ksteps;
-      if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
-      else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
+      if constexpr (!(DBG & 16)) {
+        if (!(DBG & 1) || kt == 0) {
+          if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
+          else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
+        }
+      }
+      // DBG & 16: the eight LDS-DMA requests of this wave are issued one at a time between the MFMAs of the first two quadrants
+      const bool dma_on = more || has_next;
+      const int dm0 = more ? m0 : m0n, dn0 = more ? n0 : n0n, dk0 = more ? (kt + 1) * BK : 0;
+      auto dma_piece = [&](int j) {
+        if (!dma_on) return;
+        char* buf = smem + (cur ^ 1) * BUF + (j >> 1) * TILE_BYTES;
+        const int q = wave * 2 + (j & 1);
+        if (j < 4) stage_one<A_KM>(ra, buf, p.lda, dm0 + (j >> 1) * 128, dk0, q, lane);
+        else stage_one<B_KM>(rb, buf, p.ldb, dn0 + ((j >> 1) - 2) * 128, dk0, q, lane);
+      };
       const char* ta = smem + cur * BUF + wr * TILE_BYTES;
       const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
       const int bcol = (wc & 1) * 64;
-      bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+      const unsigned long long s0 = SA_STAMP();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[i][j]);
+            if constexpr ((DBG & 16) != 0) if (j == 1 && (i & 1)) dma_piece(ks * 2 + (i >> 1));
+          }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) {
+            acc[i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[i][2 + j]);
+            if constexpr ((DBG & 16) != 0) if (j == 1 && (i & 1)) dma_piece(4 + ks * 2 + (i >> 1));
+          }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2)) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j]);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
-      if (more) {
+          for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[4 + i][j]);
+      if constexpr (DBG & 8) {
+        asm volatile("s_nop 0" ::"v"(acc[4][0]), "v"(acc[7][1]));   // the last MFMA results exist: the section really ended
+        const unsigned long long s1 = SA_STAMP();
+        pc_mfma += s1 - s0;
+        ++pc_steps;
+        if (more) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long s2 = SA_STAMP();
+          __builtin_amdgcn_s_barrier();
+          const unsigned long long s3 = SA_STAMP();
+          pc_vm += s2 - s1;
+          pc_bar += s3 - s2;
+          cur ^= 1;
+        }
+      } else if (more) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
       }
     }
+    const unsigned long long e0 = SA_STAMP();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // raw: the next tile's LDS-DMA stays in flight
     char* wl = smem + cur * BUF + wave * 8192;
     wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
     wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    pc_epi += SA_STAMP() - e0;
     if (!has_next) break;
     t = tnext; m0 = m0n; n0 = n0n;
     cur ^= 1;
+  }
+  if constexpr (DBG & 8) {
+    const int which = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
+    if (which >= 0 && threadIdx.x == 64 * 5) {          // wave 5 of two workgroups
+      unsigned long long* o = sa_gemm_prof[which];
+      o[0] = pc_steps; o[1] = pc_mfma; o[2] = pc_vm; o[3] = pc_bar; o[4] = pc_epi; o[5] = SA_STAMP() - pc_begin; o[6] = pc_top;
+    }
   }
 }
 
@@ -1050,8 +1158,439 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
                               8 * TILE_BYTES);
   }
   const int ntiles = p.tiles_m * p.tiles_n;
+  if constexpr (A_KM && B_KM) {
+    static const char* dbg = getenv("SA_GEMM_DBG");
+    if (dbg && atoi(dbg) > 0) {
+      const dim3 g(ntiles < slots ? ntiles : slots), b(512);
+#define SA_DBG_CASE(D)                                                                                                     \
+  case D:                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, D>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                                 \
+    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, D>), g, b, 8 * TILE_BYTES, stream, p);                           \
+    break;
+      switch (atoi(dbg)) { SA_DBG_CASE(1) SA_DBG_CASE(2) SA_DBG_CASE(3) SA_DBG_CASE(4) SA_DBG_CASE(5) SA_DBG_CASE(6) SA_DBG_CASE(7) SA_DBG_CASE(8) SA_DBG_CASE(16) SA_DBG_CASE(24) SA_DBG_CASE(32) SA_DBG_CASE(40) }
+#undef SA_DBG_CASE
+      SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, dbg)");
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
+  return 0;
+}
+
+
+// =====================================================================================================
+// Persistent 256 x 256 x 64 kernel, software-pipelined across the K-step barrier ("mode 7").
+// The lock-step kernel above starts every K-step with all 8 waves issuing 12 KiB of fragment reads at once and the MFMA
+// pipe idle until they drain.  Here the K-step barrier sits three quarters of the way through the step: quadrants
+// Q0..Q2 run, then (vmcnt(0) + barrier) proves the NEXT stage has landed and THIS stage is no longer read, the LDS-DMA
+// for K-tile g+2 is requested into this stage, the first fragments of K-tile g+1 are read, and only then does Q3 (whose
+// operands are already in registers) issue -- so the fragment reads that open a K-step always overlap 16 MFMAs.  The
+// quadrant order mirrors on odd steps (B-low / B-high swap roles) so the prefetch always targets registers that are dead.
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
+  constexpr int BUF = 4 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  auto coords = [&](int t, int& m0, int& n0) {
+    const int grp = t / group_sz, within = t - grp * group_sz;
+    const int gm = min(GM, p.tiles_m - grp * GM);
+    m0 = (grp * GM + within % gm) * 256;
+    n0 = (within / gm) * 256;
+  };
+  const int ksteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  int t = lid;
+  if (t >= ntiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+
+  // request cursor: the next K-tile (tile rt at rm0/rn0, K-step rk) to bring in; runs ahead of the compute by 2 K-tiles
+  int rt = t, rm0 = m0, rn0 = n0, rk = 0;
+  auto request = [&](char* buf) {
+    if (rt >= ntiles) return;
+    stage_tile<A_KM, 8>(ra, buf, p.lda, rm0, rk * BK, wave, lane);
+    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, rm0 + 128, rk * BK, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, rn0, rk * BK, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, rn0 + 128, rk * BK, wave, lane);
+    if (++rk == ksteps) {
+      rk = 0;
+      rt += nwg;
+      if (rt < ntiles) coords(rt, rm0, rn0);
+    }
+  };
+
+  request(smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  request(smem + BUF);
+  int cur = 0;
+  const int bcol = (wc & 1) * 64;
+
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fal[4][2], fah[4][2], fb[2][2][2];   // A rows 0..63 / 64..127 of the wave tile; B columns [half][j][ks]
+    {
+      const char* ta = smem + cur * BUF + wr * TILE_BYTES;
+      const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fal[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb[0][j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+    }
+
+    auto step = [&](auto parity, bool last) {
+      constexpr int P = decltype(parity)::value, O = 1 - P;
+      const char* ta = smem + cur * BUF + wr * TILE_BYTES;
+      const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb[O][j][ks] = load_frag<B_KM>(tb, bcol + O * 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fah[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 * P + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j][ks], fal[i][ks], acc[i][2 * P + j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 * O + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[O][j][ks], fal[i][ks], acc[i][2 * O + j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 * O + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[O][j][ks], fah[i][ks], acc[4 + i][2 * O + j], 0, 0, 0);
+      // ---- the K-step barrier: next stage landed, this stage dead
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!last) {
+        request(smem + cur * BUF);
+        const char* na = smem + (cur ^ 1) * BUF + wr * TILE_BYTES;
+        const char* nb = smem + (cur ^ 1) * BUF + (2 + (wc >> 1)) * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fal[i][ks] = load_frag<A_KM>(na, i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fb[O][j][ks] = load_frag<B_KM>(nb, bcol + O * 32 + j * 16, ks, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 * P + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j][ks], fah[i][ks], acc[4 + i][2 * P + j], 0, 0, 0);
+      cur ^= 1;
+    };
+
+    for (int kt = 0; kt < ksteps; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt + 1 == ksteps);
+      if (kt + 1 < ksteps) step(std::integral_constant<int, 1>{}, kt + 2 == ksteps);
+    }
+    // epilogue: stage through the K-stage consumed last (every wave is past its barrier, so nobody reads it any more)
+    char* wl = smem + (cur ^ 1) * BUF + wave * 8192;
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    t += nwg;
+    if (t >= ntiles) break;
+    coords(t, m0, n0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // all epilogue scratch reads done: the stage may be refilled
+    request(smem + (cur ^ 1) * BUF);
+  }
+}
+
+template <bool A_KM, bool B_KM>
+int launch256_pp(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: cannot query the device");
+      return 2;
+    }
+    slots = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pp_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              8 * TILE_BYTES);
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((gemm256_pp_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256 pipelined)");
+  return 0;
+}
+
+
+// =====================================================================================================
+// Persistent 256 x 256 x 64 kernel over a FIVE-slot ring of 32 KiB half-stages ("mode 8"; forward / dgrad and split-K wgrad).
+// Measured with scripts/microbench/dma_bw.hip: one workgroup per CU streams operand tiles L2 -> LDS at ~23 B/clk/CU with one
+// 64 KiB stage in flight and ~34 B/clk/CU with two -- the 256^2 tile needs 32 B/clk/CU at MFMA peak, so bytes in flight are
+// the limiter, and 160 KiB of LDS cannot hold three 64 KiB stages.  Splitting a stage into its A half and B half lets the
+// whole LDS work as a ring: two halves are being read, THREE are in flight (the K-tile after next's A half included).
+//   slot(h) = h mod 5 for the h-th half-tile of this workgroup's K-tile stream (A_0 B_0 A_1 B_1 ...), across tile borders;
+//   end of K-step g: s_waitcnt vmcnt(4) leaves only A_{g+2} outstanding, barrier, then B_{g+2} and A_{g+3} are requested
+//   into the two slots step g has just finished reading.
+// Requests past the end of the stream go out of range (zero fill, no traffic) so the outstanding count stays exact; the
+// K-step right after an epilogue waits vmcnt(0) because stores / atomics sit between the loads in the counter.
+template <bool A_KM, bool B_KM, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF = 2 * TILE_BYTES;               // 32 KiB: [rows 0..127 | rows 128..255] of one operand
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nunits = ntiles * (SPLIT ? p.split_k : 1);
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  const int ksteps_all = (p.K + BK - 1) / BK;
+  const int chunk = SPLIT ? (ksteps_all + p.split_k - 1) / p.split_k : ksteps_all;
+  // unit -> (m0, n0, first K-step, number of K-steps); split-K slice slowest so co-resident workgroups share K rows in L2
+  auto unit = [&](int u, int& m0, int& n0, int& kt0, int& nk) {
+    const int ks_id = SPLIT ? u / ntiles : 0;
+    const int t = u - ks_id * ntiles;
+    const int grp = t / group_sz, within = t - grp * group_sz;
+    const int gm = min(GM, p.tiles_m - grp * GM);
+    m0 = (grp * GM + within % gm) * 256;
+    n0 = (within / gm) * 256;
+    kt0 = ks_id * chunk;
+    nk = min(ksteps_all - kt0, chunk);
+  };
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  int u = lid;
+  if (u >= nunits) return;
+  int m0, n0, kt0, nk;
+  unit(u, m0, n0, kt0, nk);
+
+  // ---- request cursor (runs 2.5 K-tiles ahead of the compute)
+  int ru = u, rm0 = m0, rn0 = n0, rk = kt0, rkend = kt0 + nk, rside = 0, rslot = 0;
+  struct HalfReq { int row0, k0, slot, valid; };      // one pending half-tile request (A if issued on an even turn, else B)
+  auto next_half = [&]() {                             // advance the cursor, return what to fetch
+    HalfReq h;
+    h.valid = ru < nunits;
+    h.slot = rslot;
+    h.k0 = rk * BK;
+    h.row0 = rside == 0 ? rm0 : rn0;
+    if (rside == 1) {
+      if (h.valid && ++rk == rkend) {
+        ru += nwg;
+        if (ru < nunits) {
+          int nk2;
+          unit(ru, rm0, rn0, rk, nk2);
+          rkend = rk + nk2;
+        }
+      }
+    }
+    rside ^= 1;
+    rslot = rslot == 4 ? 0 : rslot + 1;
+    return h;
+  };
+  // piece i (0..3) of a half: this wave's instruction (i & 1) of 16-KiB tile (i >> 1)
+  auto issue_a = [&](const HalfReq& h, int i) {
+    stage_one_v<A_KM>(ra, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.lda, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
+  };
+  auto issue_b = [&](const HalfReq& h, int i) {
+    stage_one_v<B_KM>(rb, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.ldb, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
+  };
+  auto request_half = [&]() {                          // burst form (prologue, after an epilogue)
+    const bool is_a = rside == 0;
+    const HalfReq h = next_half();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (is_a) issue_a(h, i); else issue_b(h, i);
+    }
+  };
+#pragma unroll 1
+  for (int i = 0; i < 5; ++i) request_half();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // A_0, B_0 landed; A_1, B_1, A_2 in flight
+  __builtin_amdgcn_s_barrier();
+
+  int ca = 0, cb = 1;                                    // slots of the K-tile being consumed
+  HalfReq pb = {0, 0, 0, 0}, pa = {0, 0, 0, 0};         // requests to trickle out during the current K-step (B half first)
+  bool pending = false;
+  bool fresh = false;
+  const int bcol = (wc & 1) * 64;
+#define SA_MM(FA, FB, ACC) (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA, FB, ACC, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB, FA, ACC, 0, 0, 0))
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ea = 0, eb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* ta = smem + ca * HALF + wr * TILE_BYTES;
+      const char* tb = smem + cb * HALF + (wc >> 1) * TILE_BYTES;
+      bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = SA_MM(fa[i][ks], fb0[j][ks], acc[i][j]);
+            if (i == 3 && j == 1 && pending) issue_b(pb, ks);          // requests trickle out every 8 MFMAs: a burst of 8 stalls
+          }                                                              // every wave on the memory pipe's issue queue
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][2 + j] = SA_MM(fa[i][ks], fb1[j][ks], acc[i][2 + j]);
+            if (i == 3 && j == 1 && pending) issue_b(pb, 2 + ks);
+          }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[4 + i][2 + j] = SA_MM(fa[i][ks], fb1[j][ks], acc[4 + i][2 + j]);
+            if (i == 3 && j == 1 && pending) issue_a(pa, ks);
+          }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[4 + i][j] = SA_MM(fa[i][ks], fb0[j][ks], acc[4 + i][j]);
+            if (i == 3 && j == 1 && pending) issue_a(pa, 2 + ks);
+          }
+      // ---- K-step barrier: the next K-tile has landed, this one is no longer read
+      if (fresh) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      pending = false;
+      if (kt + 1 < nk) {
+        pb = next_half();                               // B_{g+2}: due at the end of the next step -> first half of it
+        pa = next_half();                               // A_{g+3}: a step of slack -> second half
+        pending = true;
+        fresh = false;
+      } else {
+        ea = ca; eb = cb;                               // the unit's epilogue borrows these two slots first
+      }
+      ca = ca >= 3 ? ca - 3 : ca + 2;
+      cb = cb >= 3 ? cb - 3 : cb + 2;
+    }
+    if constexpr (SPLIT) {
+      const int g = lane >> 4, c = lane & 15;           // lane owns rows 4g + r of one column -> 64-byte row segments per atomic
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 128 + i * 16 + 4 * g + r;
+            if (m < p.M && n < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+          }
+        }
+    } else {
+      char* wl = smem + (wave < 4 ? ea * HALF + wave * 8192 : eb * HALF + (wave - 4) * 8192);
+      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    }
+    u += nwg;
+    if (u >= nunits) break;
+    unit(u, m0, n0, kt0, nk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave is done with its epilogue scratch
+    request_half();
+    request_half();
+    fresh = true;
+  }
+#undef SA_MM
+}
+
+template <bool A_KM, bool B_KM, bool SPLIT>
+int launch256_ring(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  if (SPLIT) {                                          // no empty K slices: the kernel's two cursors must agree on the unit list
+    const int ksteps_all = (p.K + BK - 1) / BK;
+    const int chunk = (ksteps_all + p.split_k - 1) / p.split_k;
+    p.split_k = (ksteps_all + chunk - 1) / chunk;
+  } else {
+    p.split_k = 1;
+  }
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: cannot query the device");
+      return 2;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_ring_kernel<A_KM, B_KM, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            10 * TILE_BYTES) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: 160 KiB of LDS per workgroup refused");
+      return 2;
+    }
+    slots = prop.multiProcessorCount;
+  }
+  const int nunits = p.tiles_m * p.tiles_n * p.split_k;
+  hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), dim3(nunits < slots ? nunits : slots), dim3(512), 10 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256 ring)");
   return 0;
 }
 
@@ -1129,6 +1668,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
 
 }  // namespace
 
+extern "C" int sa_gemm_debug_counters(uint64_t* out16) {
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpyFromSymbol(out16, HIP_SYMBOL(sa_gemm_prof), 16 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    sa_set_error("sa_gemm_debug_counters: copy failed");
+    return 2;
+  }
+  return 0;
+}
+
 extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SA_CHECK_ARG(a != nullptr, "sa_gemm_bf16: null args");
@@ -1181,7 +1729,22 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   // those stay selectable through SA_GEMM_TILE for experiments and are parity-tested.
   // default for large problems: mode 6, the persistent 256 x 256 kernel (measured 12 % faster than mode 1 over the ViT-B
   // forward + dgrad shapes: scripts/bench_gemm.py); small / ragged problems use the plain 128 x 128 kernel.
-  const char mode = force ? force[0] : (big ? '6' : '1');
+  // mode 8 (five-slot half-stage ring, requests trickled between MFMAs) measured 8-13 % faster than mode 6 on the dgrad (NN,
+  // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
+  const char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
+  if (mode == '8' && a->split_k == 1) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, false>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256_ring<true, false, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256_ring<false, true, false>(p, stream);
+    return launch256_ring<false, false, false>(p, stream);
+  }
+  if (mode == '7' && a->split_k == 1 && a->K >= 128) {
+    if (a->a_kmajor && a->b_kmajor) return launch256_pp<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256_pp<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256_pp<false, true>(p, stream);
+    return launch256_pp<false, false>(p, stream);
+  }
   if (mode == '6' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     if (a->a_kmajor && a->b_kmajor) return launch256_persist<true, true>(p, stream);
@@ -1216,6 +1779,13 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   }
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    static const char* wring = getenv("SA_GEMM_WGRAD_RING");
+    if (wring && wring[0] == '1') {
+      if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, true>(p, stream);
+      if (a->a_kmajor && !a->b_kmajor) return launch256_ring<true, false, true>(p, stream);
+      if (!a->a_kmajor && a->b_kmajor) return launch256_ring<false, true, true>(p, stream);
+      return launch256_ring<false, false, true>(p, stream);
+    }
     if (a->a_kmajor && a->b_kmajor) return launch256<true, true, true>(p, stream);
     if (a->a_kmajor && !a->b_kmajor) return launch256<true, false, true>(p, stream);
     if (!a->a_kmajor && a->b_kmajor) return launch256<false, true, true>(p, stream);

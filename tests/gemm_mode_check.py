@@ -1,0 +1,59 @@
+"""Helper for test_kernels_gpu.py::test_gemm_tile_modes: run in a subprocess with SA_GEMM_TILE / SA_GEMM_WGRAD_RING set
+(the library reads them once), checks every operand layout of a large ragged problem against an fp64 CPU product."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ssl_audio_amd import ops
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def main():
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4000, 2104, 192 + 64          # 16 x 9 = 144 tiles of 256 x 256 -> the large-problem kernels; ragged M and N
+    A = bf(torch.randn(M, K, generator=g)); B = bf(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g); res = torch.randn(M, N, generator=g)
+    acc = A.double() @ B.double().T
+    worst = 0.0
+    for a_km in (True, False):
+        for b_km in (True, False):
+            Ad = (A if a_km else A.T.contiguous()).to(dev)
+            Bd = (B if b_km else B.T.contiguous()).to(dev)
+            out32 = torch.full((M, N), float("nan"), device=dev)
+            out16 = torch.empty(M, N + 4, device=dev, dtype=torch.bfloat16)[:, :N]      # strided output rows
+            ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, bias=bias.to(dev), residual=res.to(dev), out_f32=out32, out_bf16=out16)
+            ref = acc + bias.double() + res.double()
+            e32 = float((out32.cpu().double() - ref).norm() / ref.norm())
+            e16 = float((out16.cpu().double() - ref).norm() / ref.norm())
+            assert e32 < 1e-5 and e16 < 4e-3, (a_km, b_km, e32, e16)
+            worst = max(worst, e32)
+    # GELU epilogue with the pre-activation side output (forward fc1) and its derivative (dgrad through fc2)
+    pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16); h = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), B.to(dev), bias=bias.to(dev), act=1, aux_out=pre, out_bf16=h)
+    x = acc + bias.double()
+    assert float((pre.cpu().double() - x).norm() / x.norm()) < 4e-3
+    gx = torch.nn.functional.gelu(x)
+    assert float((h.cpu().double() - gx).norm() / gx.norm()) < 4e-3
+    d = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), B.to(dev), act=2, aux_in=pre, out_bf16=d)
+    xx = pre.cpu().double().requires_grad_(True)
+    torch.nn.functional.gelu(xx).sum().backward()
+    refd = acc * xx.grad
+    assert float((d.cpu().double() - refd).norm() / refd.norm()) < 4e-3
+    # split-K wgrad on the 256 tile (TN), ragged reduction
+    T, Nw, Kw = 9000 + 17, 704, 1032
+    dY = bf(torch.randn(T, Nw, generator=g)); X = bf(torch.randn(T, Kw, generator=g))
+    out = torch.zeros(Nw, Kw, device=dev)
+    ops.gemm(dY.to(dev), X.to(dev), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=ops.pick_split_k(Nw, Kw, T, tile=256), tile256=True)
+    refw = dY.double().T @ X.double()
+    ew = float((out.cpu().double() - refw).norm() / refw.norm())
+    assert ew < 1e-5, ew
+    torch.cuda.synchronize()
+    print(f"ok tile={os.environ.get('SA_GEMM_TILE', 'default')} ring_wgrad={os.environ.get('SA_GEMM_WGRAD_RING', '0')} worst={worst:.2e} wgrad={ew:.2e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,17 @@ def test_gemm_split_k_wgrad(dev):
     assert rel_err(out, 0.5 * (dY.double().T @ X.double())) < 1e-5
 
 
+@pytest.mark.parametrize("env", [{}, {"SA_GEMM_TILE": "6"}, {"SA_GEMM_TILE": "8", "SA_GEMM_WGRAD_RING": "1"}, {"SA_GEMM_TILE": "2"},
+                                 {"SA_GEMM_TILE": "3"}, {"SA_GEMM_TILE": "5"}, {"SA_GEMM_TILE": "7"}, {"SA_GEMM_TILE": "1"}])
+def test_gemm_tile_modes(dev, env):
+    """Large ragged problem through every tile variant of sa_gemm_bf16 (default dispatch first).  The variant is chosen by an
+    environment variable the library reads once, hence one subprocess per variant (sequential: one GPU process at a time)."""
+    import os, subprocess, sys
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "gemm_mode_check.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok tile=" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_cast_and_colsum(dev):
     x = rnd((1000, 300), 10)
     y = ops.cast_bf16(x.to(dev))
