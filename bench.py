@@ -29,7 +29,7 @@ GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(workload, budget_clips=4, steps=2):
+def cpu_baseline(workload, budget_clips=8, steps=16):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
     from oracle import step as ostep, vit as ovit
     from ssl_audio_amd.selfcheck import synthetic_waveforms
@@ -67,11 +67,11 @@ def cpu_baseline(workload, budget_clips=4, steps=2):
         return ostep.bt_step(sd, views, heads, (4, 6), opt)[0]
 
     t0 = time.time()
-    one_step(2)                                   # warm-up on 2 clips (also sizes the sample: stay within ~30 s of CPU work)
+    one_step(2)                                   # warm-up on 2 clips (also sizes the sample: about 15 s of CPU work)
     warm = (time.time() - t0) * budget_clips / 2
     print(f"[bench] cpu baseline warm-up: ~{warm:.1f}s per {budget_clips}-clip step on {cores} threads ({avail} cores visible)",
           file=sys.stderr, flush=True)
-    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))
+    steps = max(1, min(steps, int(15.0 / max(warm, 1e-3))))   # about 15 s of CPU work, never more than `steps` steps
     t0 = time.time()
     for _ in range(steps):
         one_step()
