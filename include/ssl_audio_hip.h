@@ -167,6 +167,27 @@ int sa_gather_rows(const float* src, int64_t src_seq_stride, int32_t src_row0, c
 int sa_scatter_add_rows(const float* src, int64_t src_seq_stride, int32_t src_row0, const int32_t* idx, int32_t n_idx, float* dst,
                         int64_t dst_seq_stride, int32_t dst_row0, int32_t S, int32_t d, void* stream);
 
+/* mean pooling of the patch tokens (`x[:, 1:].mean(dim=1)`, models/mae.py:461-462) and its adjoint (row 0 gets zero) */
+int sa_mean_tokens_fwd(const float* y, int32_t S, int32_t N, int32_t d, float* out, void* stream);
+int sa_mean_tokens_bwd(const float* dout, int32_t S, int32_t N, int32_t d, float* dy, void* stream);
+
+/* MAE decoder input (forward_decoder, models/mae.py:413-420): mask tokens appended, un-shuffled by ids_restore, decoder
+ * positional table added.  x [B][1+keep][d], out [B][1+L][d]; bwd WRITES dx (kept rows are a permutation) and ADDS the
+ * masked rows into dmask_token. */
+int sa_mae_unshuffle_fwd(const float* x, int32_t keep, const float* mask_token, const float* pos, const int32_t* ids_restore, int32_t B,
+                         int32_t L, int32_t d, float* out, void* stream);
+int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32_t* ids_restore, int32_t B, int32_t L, int32_t d, float* dx,
+                         float* dmask_token, void* stream);
+
+/* MAE reconstruction loss (forward_loss + patchify, models/mae.py:437-453, :282-293; one input channel, norm_pix_loss off):
+ * loss = sum_l mask * mean_p (pred - patchify(img))^2 / sum mask.  acc2 = {numerator, sum mask} (kept for the backward);
+ * bwd: dpred = gscale[0] * 2 * mask * (pred - target) / (P * sum mask).  pred / dpred are [B][pred_row0 + L][P] with
+ * pred_seq_stride elements per clip: pred_row0 = 1 reads decoder_pred's output in place (its CLS row gets gradient 0). */
+int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
+                          float* acc2, float* loss, void* stream);
+int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
+                          int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

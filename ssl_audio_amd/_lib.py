@@ -41,6 +41,12 @@ _SIGNATURES = {
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
     "sa_layernorm_bwd_workspace_bytes": [I32, I32],
     "sa_gemm_debug_counters": [P],
+    "sa_mean_tokens_fwd": [P, I32, I32, I32, P, P],
+    "sa_mean_tokens_bwd": [P, I32, I32, I32, P, P],
+    "sa_mae_unshuffle_fwd": [P, I32, P, P, P, I32, I32, I32, P, P],
+    "sa_mae_unshuffle_bwd": [P, I32, P, I32, I32, I32, P, P, P],
+    "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, P, P, P],
+    "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -57,6 +57,160 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t s
   }
 }
 
+
+// ---- mean pooling over the patch tokens (rows 1..N-1) of a [S][N][d] sequence (models/mae.py:461-462) and its adjoint
+__global__ void mean_tokens_kernel(const float* __restrict__ y, int S, int N, int d, float* __restrict__ out) {
+  const int nv = d >> 2;
+  const int64_t n = (int64_t)S * nv;
+  const float inv = 1.f / (float)(N - 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv), s = (int)(i / nv);
+    const float4* p = reinterpret_cast<const float4*>(y + ((int64_t)s * N + 1) * d) + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < N - 1; ++r) {
+      const float4 v = p[(int64_t)r * nv];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out + (int64_t)s * d)[c] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  }
+}
+
+__global__ void mean_tokens_bwd_kernel(const float* __restrict__ dout, int S, int N, int d, float* __restrict__ dy) {
+  const int nv = d >> 2;
+  const int64_t n = (int64_t)S * N * nv;
+  const float inv = 1.f / (float)(N - 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv);
+    const int64_t sr = i / nv;
+    const int r = (int)(sr % N), s = (int)(sr / N);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r > 0) {
+      const float4 g = reinterpret_cast<const float4*>(dout + (int64_t)s * d)[c];
+      v = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    }
+    reinterpret_cast<float4*>(dy)[i] = v;
+  }
+}
+
+// ---- MAE decoder input (models/mae.py:413-420): out[b][0] = x[b][0] + pos[0];
+// out[b][1 + l] = (ids_restore[b][l] < keep ? x[b][1 + ids_restore[b][l]] : mask_token) + pos[1 + l]
+__global__ void mae_unshuffle_kernel(const float* __restrict__ x, int keep, const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                     const int* __restrict__ ids_restore, int B, int L, int d, float* __restrict__ out) {
+  const int nv = d >> 2;
+  const int64_t n = (int64_t)B * (L + 1) * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv);
+    const int64_t br = i / nv;
+    const int row = (int)(br % (L + 1)), b = (int)(br / (L + 1));
+    float4 v;
+    if (row == 0) {
+      v = reinterpret_cast<const float4*>(x + (int64_t)b * (keep + 1) * d)[c];
+    } else {
+      const int r = ids_restore[(int64_t)b * L + row - 1];
+      v = r < keep ? reinterpret_cast<const float4*>(x + ((int64_t)b * (keep + 1) + 1 + r) * d)[c] : reinterpret_cast<const float4*>(mask_token)[c];
+    }
+    const float4 pz = reinterpret_cast<const float4*>(pos + (int64_t)row * d)[c];
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x + pz.x, v.y + pz.y, v.z + pz.z, v.w + pz.w);
+  }
+}
+
+// adjoint: dx rows are a permutation of the kept rows of dout (written, not accumulated); dmask_token += sum over masked rows.
+// One block column per 64 float4 columns, blockIdx.y strides over (b, row); the mask-token partial stays in registers.
+__global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __restrict__ dout, int keep, const int* __restrict__ ids_restore, int B, int L,
+                                                                int d, float* __restrict__ dx, float* __restrict__ dmask) {
+  __shared__ float4 red[4][64];
+  const int nv = d >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t rows = (int64_t)B * (L + 1);
+  for (int64_t br = (int64_t)blockIdx.y * 4 + wave; br < rows; br += (int64_t)gridDim.y * 4) {
+    if (c >= nv) break;
+    const int row = (int)(br % (L + 1)), b = (int)(br / (L + 1));
+    const float4 g = reinterpret_cast<const float4*>(dout + br * d)[c];
+    if (row == 0) {
+      reinterpret_cast<float4*>(dx + (int64_t)b * (keep + 1) * d)[c] = g;
+    } else {
+      const int r = ids_restore[(int64_t)b * L + row - 1];
+      if (r < keep) reinterpret_cast<float4*>(dx + ((int64_t)b * (keep + 1) + 1 + r) * d)[c] = g;
+      else { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; }
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < nv && dmask) {
+    float4 t = red[0][lane];
+    for (int w = 1; w < 4; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+    atomicAdd(dmask + 4 * c + 0, t.x); atomicAdd(dmask + 4 * c + 1, t.y);
+    atomicAdd(dmask + 4 * c + 2, t.z); atomicAdd(dmask + 4 * c + 3, t.w);
+  }
+}
+
+// ---- MAE reconstruction loss (models/mae.py:437-453, patchify :282-293; one input channel):
+// target[b][l][py*pw + px] = img[b][gy*ph + py][gx*pw + px], l = gy*gw + gx;  loss = sum_l mask * mean_p (pred - target)^2 / sum mask.
+// Pass 1: one wave per (b, l) row -> acc[0] += mask * mean_p (.)^2, acc[1] += mask.   Pass 2 (finalize): loss = acc[0] / acc[1].
+__global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restrict__ pred, int64_t pred_seq_stride, int pred_row0,
+                                                            const float* __restrict__ img, const float* __restrict__ mask,
+                                                            int B, int F, int T, int ph, int pw, float* __restrict__ acc) {
+  __shared__ float red[8];
+  const int gh = F / ph, gw = T / pw, L = gh * gw, P = ph * pw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float num = 0.f, den = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < (int64_t)B * L; row += (int64_t)gridDim.x * 4) {
+    const float m = mask[row];
+    if (lane == 0) den += m;
+    if (m == 0.f) continue;                               // visible patches do not enter the loss
+    const int l = (int)(row % L), b = (int)(row / L);
+    const int gy = l / gw, gx = l % gw;
+    const float* ip = img + ((int64_t)b * F + (int64_t)gy * ph) * T + (int64_t)gx * pw;
+    const float* pr = pred + (int64_t)b * pred_seq_stride + (int64_t)(pred_row0 + l) * P;
+    float s = 0.f;
+    for (int p = lane; p < P; p += 64) {
+      const float t = ip[(int64_t)(p / pw) * T + (p % pw)];
+      const float e = pr[p] - t;
+      s += e * e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) num += m * s / (float)P;
+  }
+  num = wave_sum(num); den = wave_sum(den);
+  if (lane == 0) { red[wave] = num; red[4 + wave] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+__global__ void mae_loss_finalize_kernel(const float* __restrict__ acc, float* __restrict__ loss) { loss[0] = acc[0] / acc[1]; }
+
+// dpred[b][row0 + l][p] = gscale * 2 * mask * (pred - target) / (P * sum mask), rows below row0 (the CLS prediction) get 0;
+// pred / dpred share the [B][row0 + L][P] layout (seq_stride elements per clip).  gscale = upstream gradient (device scalar).
+__global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, int64_t seq_stride, int row0, const float* __restrict__ img,
+                                    const float* __restrict__ mask, const float* __restrict__ acc, const float* __restrict__ gscale, int B,
+                                    int F, int T, int ph, int pw, float* __restrict__ dpred) {
+  const int gh = F / ph, gw = T / pw, L = gh * gw, P = ph * pw;
+  const int64_t n = (int64_t)B * (row0 + L) * P;
+  const float k = gscale[0] * 2.f / ((float)P * acc[1]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    const int64_t br = i / P;
+    const int r = (int)(br % (row0 + L)), b = (int)(br / (row0 + L));
+    float v = 0.f;
+    const int64_t off = (int64_t)b * seq_stride + (int64_t)r * P + p;
+    if (r >= row0) {
+      const int l = r - row0;
+      const float m = mask[(int64_t)b * L + l];
+      if (m != 0.f) {
+        const int gy = l / gw, gx = l % gw;
+        const float t = img[((int64_t)b * F + (int64_t)gy * ph + p / pw) * T + (int64_t)gx * pw + (p % pw)];
+        v = k * m * (pred[off] - t);
+      }
+    }
+    dpred[off] = v;
+  }
+}
+
 inline int grid_for(int64_t n) {
   const int64_t want = (n + 255) / 256;
   return (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
@@ -94,5 +248,70 @@ extern "C" int sa_scatter_add_rows(const float* src, int64_t src_seq_stride, int
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((int64_t)S * n_idx * (d / 4))), dim3(256), 0, (hipStream_t)stream, src,
                      src_seq_stride, src_row0, idx, n_idx, dst, dst_seq_stride, dst_row0, S, d);
   SA_LAUNCH_CHECK("sa_scatter_add_rows");
+  return 0;
+}
+
+extern "C" int sa_mean_tokens_fwd(const float* y, int32_t S, int32_t N, int32_t d, float* out, void* stream) {
+  SA_CHECK_ARG(y && out && S > 0 && N > 1 && d > 0 && d % 4 == 0, "sa_mean_tokens_fwd: bad args (need N > 1, d %% 4 == 0)");
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(grid_for((int64_t)S * (d / 4))), dim3(256), 0, (hipStream_t)stream, y, S, N, d, out);
+  SA_LAUNCH_CHECK("sa_mean_tokens_fwd");
+  return 0;
+}
+
+extern "C" int sa_mean_tokens_bwd(const float* dout, int32_t S, int32_t N, int32_t d, float* dy, void* stream) {
+  SA_CHECK_ARG(dout && dy && S > 0 && N > 1 && d > 0 && d % 4 == 0, "sa_mean_tokens_bwd: bad args (need N > 1, d %% 4 == 0)");
+  hipLaunchKernelGGL(mean_tokens_bwd_kernel, dim3(grid_for((int64_t)S * N * (d / 4))), dim3(256), 0, (hipStream_t)stream, dout, S, N, d, dy);
+  SA_LAUNCH_CHECK("sa_mean_tokens_bwd");
+  return 0;
+}
+
+extern "C" int sa_mae_unshuffle_fwd(const float* x, int32_t keep, const float* mask_token, const float* pos, const int32_t* ids_restore, int32_t B,
+                                    int32_t L, int32_t d, float* out, void* stream) {
+  SA_CHECK_ARG(x && mask_token && pos && ids_restore && out && B > 0 && L > 0 && keep >= 0 && keep <= L && d > 0 && d % 4 == 0,
+               "sa_mae_unshuffle_fwd: bad args");
+  hipLaunchKernelGGL(mae_unshuffle_kernel, dim3(grid_for((int64_t)B * (L + 1) * (d / 4))), dim3(256), 0, (hipStream_t)stream, x, keep, mask_token,
+                     pos, ids_restore, B, L, d, out);
+  SA_LAUNCH_CHECK("sa_mae_unshuffle_fwd");
+  return 0;
+}
+
+extern "C" int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32_t* ids_restore, int32_t B, int32_t L, int32_t d, float* dx,
+                                    float* dmask_token, void* stream) {
+  SA_CHECK_ARG(dout && ids_restore && dx && B > 0 && L > 0 && keep >= 0 && keep <= L && d > 0 && d % 4 == 0, "sa_mae_unshuffle_bwd: bad args");
+  const int64_t rows = (int64_t)B * (L + 1);
+  int gy = (int)((rows + 3) / 4);
+  if (gy > 128) gy = 128;
+  hipLaunchKernelGGL(mae_unshuffle_bwd_kernel, dim3((d / 4 + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, dout, keep, ids_restore, B, L, d, dx,
+                     dmask_token);
+  SA_LAUNCH_CHECK("sa_mae_unshuffle_bwd");
+  return 0;
+}
+
+extern "C" int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
+                                     float* acc2, float* loss, void* stream) {
+  SA_CHECK_ARG(pred && img && mask && acc2 && loss && B > 0 && ph > 0 && pw > 0 && F >= ph && T >= pw && F % ph == 0 && T % pw == 0 &&
+                   pred_row0 >= 0 && pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw,
+               "sa_mae_recon_loss_fwd: bad args (F, T must be multiples of the patch size; pred rows must fit the clip stride)");
+  if (hipMemsetAsync(acc2, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    sa_set_error("sa_mae_recon_loss_fwd: memset failed");
+    return 2;
+  }
+  const int64_t rows = (int64_t)B * (F / ph) * (T / pw);
+  int grid = (int)((rows + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(mae_loss_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, B, F, T, ph, pw, acc2);
+  hipLaunchKernelGGL(mae_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc2, loss);
+  SA_LAUNCH_CHECK("sa_mae_recon_loss_fwd");
+  return 0;
+}
+
+extern "C" int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
+                                     int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream) {
+  SA_CHECK_ARG(pred && img && mask && acc2 && gscale && dpred && B > 0 && ph > 0 && pw > 0 && F % ph == 0 && T % pw == 0 && pred_row0 >= 0 &&
+                   pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw, "sa_mae_recon_loss_bwd: bad args");
+  const int64_t n = (int64_t)B * (pred_row0 + (F / ph) * (T / pw)) * ph * pw;
+  hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, acc2,
+                     gscale, B, F, T, ph, pw, dpred);
+  SA_LAUNCH_CHECK("sa_mae_recon_loss_bwd");
   return 0;
 }

@@ -282,7 +282,11 @@ class EncoderFn(torch.autograd.Function):
             y = torch.empty(S * N, d, device=dev)
             mean, rstd = torch.empty(S * N, device=dev), torch.empty(S * N, device=dev)
             ops.layernorm_fwd(x, nw, nb, eps, y_f32=y, mean=mean, rstd=rstd)
-            out = y.view(S, N, d)[:, 1:].mean(dim=1).contiguous() if pool == "mean" else y.view(S, N, d)
+            if pool == "mean":
+                out = torch.empty(S, d, device=dev)
+                ops.mean_tokens_fwd(y.view(S, N, d), out)
+            else:
+                out = y.view(S, N, d)
         ctx.cfg = (S, N, d, H, pool, n_blocks, cls_prune)
         ctx.saved = save
         ctx.final = (x, mean, rstd)
@@ -318,8 +322,8 @@ class EncoderFn(torch.autograd.Function):
                               dx_bf16=dx16.view(S, N * d)[:, :d], dgamma=gnw, dbeta=gnb)
         else:
             if pool == "mean":
-                dy = torch.zeros(S, N, d, device=dev)
-                dy[:, 1:] = (dout / (N - 1)).unsqueeze(1)
+                dy = torch.empty(S, N, d, device=dev)
+                ops.mean_tokens_bwd(dout, dy)
                 dy = dy.view(M, d)
             else:
                 dy = dout.reshape(M, d)

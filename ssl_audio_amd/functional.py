@@ -37,8 +37,8 @@ class TokensFn(torch.autograd.Function):
         if ids_keep is not None:
             keep = ids_keep.shape[1]
             out = torch.empty(S, 1 + keep, d, device=dev)
-            out[:, 0] = tok[:, 0]
-            ops.gather_rows(tok, (1 + L) * d, 1, ids_keep, out, (1 + keep) * d, 1, S, d)
+            rows = torch.cat([torch.zeros(S, 1, dtype=torch.int32, device=dev), ids_keep + 1], dim=1).contiguous()   # CLS row + kept patch rows
+            ops.gather_rows(tok, (1 + L) * d, 0, rows, out, (1 + keep) * d, 0, S, d)
             tok = out
         ctx.shape = tok.shape
         ctx.cls_param = cls_token
@@ -54,6 +54,79 @@ class TokensFn(torch.autograd.Function):
             ops.cls_grad(dtok, S, N * d, d, buf.view(-1))
             dcls = ret
         return None, dcls, None, None, None, None
+
+
+class MaeUnshuffleFn(torch.autograd.Function):
+    """forward_decoder's token assembly (models/mae.py:413-420): append mask tokens, un-shuffle with ids_restore, add the
+    decoder positional table.  x [B, 1+keep, d] fp32 -> [B, 1+L, d] fp32; gradients: x and mask_token."""
+
+    @staticmethod
+    def forward(ctx, x, mask_token, pos, ids_restore):
+        x = x.contiguous()
+        B, kp1, d = x.shape
+        ids = ids_restore.to(torch.int32).contiguous()
+        out = torch.empty(B, ids.shape[1] + 1, d, device=x.device)
+        ops.mae_unshuffle_fwd(x, mask_token.detach().reshape(-1).contiguous(), pos.detach().reshape(-1, d).contiguous(), ids, out)
+        ctx.save_for_backward(ids)
+        ctx.keep = kp1 - 1
+        ctx.mask_param = mask_token
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, _, d = dout.shape
+        dx = torch.empty(B, ctx.keep + 1, d, device=dout.device)
+        dmask = None
+        buf = None
+        if ctx.needs_input_grad[1]:
+            buf, dmask = grad_target(ctx.mask_param)
+        ops.mae_unshuffle_bwd(dout, ctx.keep, ids, dx, buf.view(-1) if buf is not None else None)
+        return dx, dmask, None, None
+
+
+class MaeReconLossFn(torch.autograd.Function):
+    """forward_loss (models/mae.py:437-453) with patchify folded in: masked mean of the per-patch MSE.  One input channel.
+    `pred` is decoder_pred's full output [B, row0 + L, P]; row0 = 1 skips its CLS row in place (models/mae.py:433)."""
+
+    @staticmethod
+    def forward(ctx, pred, imgs, mask, ph, pw, row0):
+        pred = pred.contiguous(); imgs = imgs.contiguous(); mask = mask.contiguous().float()
+        if imgs.shape[1] != 1:
+            raise ValueError("MaeReconLossFn: the audio path has one input channel")
+        acc2 = torch.empty(2, device=pred.device)
+        loss = torch.empty((), device=pred.device)
+        ops.mae_recon_loss_fwd(pred, row0, imgs, mask, ph, pw, acc2, loss.view(1))
+        ctx.save_for_backward(pred, imgs, mask, acc2)
+        ctx.cfg = (ph, pw, row0)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, imgs, mask, acc2 = ctx.saved_tensors
+        ph, pw, row0 = ctx.cfg
+        dpred = torch.empty_like(pred)
+        ops.mae_recon_loss_bwd(pred, row0, imgs, mask, ph, pw, acc2, g.reshape(1).float().contiguous(), dpred)
+        return dpred, None, None, None, None, None
+
+
+class MeanTokensFn(torch.autograd.Function):
+    """`x[:, 1:].mean(dim=1)` (models/mae.py:461-462) on a [S, N, d] fp32 sequence."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        out = torch.empty(x.shape[0], x.shape[2], device=x.device)
+        ops.mean_tokens_fwd(x, out)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dy = torch.empty(ctx.shape, device=dout.device)
+        ops.mean_tokens_bwd(dout.contiguous().float(), dy)
+        return dy
 
 
 class LinearFn(torch.autograd.Function):

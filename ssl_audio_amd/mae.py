@@ -210,18 +210,13 @@ class MaskedAutoencoderViT(nn.Module):
 
     def forward_decoder(self, x, ids_restore):
         x = Fn.LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
-        mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] + 1 - x.shape[1], 1)
-        x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
-        x_ = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))   # un-shuffle (data movement)
-        x = torch.cat([x[:, :1, :], x_], dim=1) + self.decoder_pos_embed
-        x = self._run_blocks(x.contiguous(), self.decoder_blocks, self.decoder_norm, self.decoder_num_heads, "all")
-        x = Fn.LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
-        return x[:, 1:, :]
+        x = Fn.MaeUnshuffleFn.apply(x, self.mask_token, self.decoder_pos_embed, ids_restore)   # mask tokens + un-shuffle + pos
+        x = self._run_blocks(x, self.decoder_blocks, self.decoder_norm, self.decoder_num_heads, "all")
+        return Fn.LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)      # [B, 1 + L, P]: CLS row kept, skipped in place by the loss
 
     def forward_loss(self, imgs, pred, mask):
-        target = self.patchify(imgs)
-        loss = ((pred - target) ** 2).mean(dim=-1)
-        return (loss * mask).sum() / mask.sum()
+        ph, pw = self.patch_size()
+        return Fn.MaeReconLossFn.apply(pred, imgs, mask, ph, pw, pred.shape[1] - mask.shape[1])   # patchify folded in; row0 = 1 when pred still has its CLS row
 
     def forward(self, imgs, mask_ratio=0, mean_pool=False, return_all=False, masked_recon=False, noise=None):
         if masked_recon or return_all:
@@ -229,7 +224,7 @@ class MaskedAutoencoderViT(nn.Module):
             if return_all:
                 latent = x
             elif mean_pool:
-                latent = torch.mean(x[:, 1:], dim=1).contiguous()
+                latent = Fn.MeanTokensFn.apply(x)
             else:
                 latent = x[:, 0].contiguous()
             if masked_recon:

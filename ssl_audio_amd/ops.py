@@ -268,6 +268,45 @@ def scatter_add_rows(src, src_seq_stride, src_row0, idx, dst, dst_seq_stride, ds
                                     _stream()), "sa_scatter_add_rows")
 
 
+def mean_tokens_fwd(y, out):
+    S, N, d = y.shape
+    check(lib().sa_mean_tokens_fwd(_p(_req(y, F32, "y")), S, N, d, _p(_req(out, F32, "out")), _stream()), "sa_mean_tokens_fwd")
+
+
+def mean_tokens_bwd(dout, dy):
+    S, N, d = dy.shape
+    check(lib().sa_mean_tokens_bwd(_p(_req(dout, F32, "dout")), S, N, d, _p(_req(dy, F32, "dy")), _stream()), "sa_mean_tokens_bwd")
+
+
+def mae_unshuffle_fwd(x, mask_token, pos, ids_restore, out):
+    B, kp1, d = x.shape
+    L = ids_restore.shape[1]
+    if ids_restore.dtype != torch.int32 or not ids_restore.is_contiguous():
+        raise ValueError("mae_unshuffle: ids_restore must be a contiguous int32 [B, L] tensor")
+    check(lib().sa_mae_unshuffle_fwd(_p(_req(x, F32, "x")), kp1 - 1, _p(_req(mask_token, F32, "mask_token")), _p(_req(pos, F32, "pos")),
+                                     _p(ids_restore), B, L, d, _p(_req(out, F32, "out")), _stream()), "sa_mae_unshuffle_fwd")
+
+
+def mae_unshuffle_bwd(dout, keep, ids_restore, dx, dmask_token):
+    B, Lp1, d = dout.shape
+    check(lib().sa_mae_unshuffle_bwd(_p(_req(dout, F32, "dout")), keep, _p(ids_restore), B, Lp1 - 1, d, _p(_req(dx, F32, "dx")),
+                                     _p(dmask_token), _stream()), "sa_mae_unshuffle_bwd")
+
+
+def mae_recon_loss_fwd(pred, row0, img, mask, ph, pw, acc2, loss):
+    """pred: contiguous [B, row0 + L, P] (row0 = 1: decoder output with its CLS row, read in place)."""
+    B, _, F_, T_ = img.shape
+    check(lib().sa_mae_recon_loss_fwd(_p(_req(pred, F32, "pred")), pred.shape[1] * pred.shape[2], row0, _p(_req(img, F32, "img")),
+                                      _p(_req(mask, F32, "mask")), B, F_, T_, ph, pw, _p(_req(acc2, F32, "acc2")), _p(_req(loss, F32, "loss")),
+                                      _stream()), "sa_mae_recon_loss_fwd")
+
+
+def mae_recon_loss_bwd(pred, row0, img, mask, ph, pw, acc2, gscale, dpred):
+    B, _, F_, T_ = img.shape
+    check(lib().sa_mae_recon_loss_bwd(_p(pred), pred.shape[1] * pred.shape[2], row0, _p(img), _p(mask), _p(acc2), _p(_req(gscale, F32, "gscale")),
+                                      B, F_, T_, ph, pw, _p(_req(dpred, F32, "dpred")), _stream()), "sa_mae_recon_loss_bwd")
+
+
 def device_info():
     name = C.create_string_buffer(128)
     cus = C.c_int32(0)

@@ -409,3 +409,67 @@ def test_attention_n_query(dev):
     assert rel_err(got, ref) < 1e-6
     mask = torch.ones(S * N, dtype=torch.bool, device=dev); mask[rows0] = False
     assert float(got[mask][:, :C_].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ MAE decoder glue, mean pooling
+def test_mean_tokens(dev):
+    S, N, d = 5, 9, 64
+    y = rnd((S, N, d), 70)
+    out = torch.empty(S, d, device=dev)
+    ops.mean_tokens_fwd(y.to(dev), out)
+    assert rel_err(out, y[:, 1:].double().mean(1)) < 1e-6
+    g = rnd((S, d), 71)
+    dy = torch.full((S, N, d), float("nan"), device=dev)
+    ops.mean_tokens_bwd(g.to(dev), dy)
+    ref = torch.zeros(S, N, d, dtype=torch.float64); ref[:, 1:] = (g.double() / (N - 1)).unsqueeze(1)
+    assert rel_err(dy, ref) < 1e-6 and float(dy[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,L,keep,d", [(3, 24, 6, 64), (2, 248, 62, 384), (2, 10, 10, 32), (2, 10, 0, 32)])
+def test_mae_unshuffle(dev, B, L, keep, d):
+    """forward_decoder's token assembly and its adjoint vs the reference formulation (cat / gather, models/mae.py:413-420)."""
+    g = torch.Generator().manual_seed(72)
+    x = torch.randn(B, 1 + keep, d, generator=g, requires_grad=True)
+    mt = torch.randn(1, 1, d, generator=g, requires_grad=True)
+    pos = torch.randn(1, 1 + L, d, generator=g)
+    ids_restore = torch.argsort(torch.argsort(torch.rand(B, L, generator=g), dim=1), dim=1)
+    mask_tokens = mt.repeat(B, L + 1 - x.shape[1], 1)
+    x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
+    x_ = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, d))
+    ref = torch.cat([x[:, :1, :], x_], dim=1) + pos
+    w = torch.randn(B, 1 + L, d, generator=g)
+    (ref * w).sum().backward()
+    out = torch.empty(B, 1 + L, d, device=dev)
+    ids = ids_restore.to(torch.int32).to(dev)
+    ops.mae_unshuffle_fwd(x.detach().to(dev), mt.detach().reshape(-1).to(dev), pos.reshape(-1, d).to(dev), ids, out)
+    assert torch.equal(out.cpu(), ref.detach())                       # pure data movement + one add: bit exact
+    dx = torch.full((B, 1 + keep, d), float("nan"), device=dev)
+    dm = torch.zeros(d, device=dev)
+    ops.mae_unshuffle_bwd(w.to(dev), keep, ids, dx, dm)
+    assert torch.equal(dx.cpu(), x.grad)
+    assert rel_err(dm, mt.grad.reshape(-1).double()) < 1e-5 if keep < L else float(dm.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,F,T,row0", [(3, 64, 96, 1), (2, 64, 992, 1), (2, 32, 48, 0)])
+def test_mae_recon_loss(dev, B, F, T, row0):
+    """forward_loss + patchify (models/mae.py:437-453, 282-293) and its gradient vs autograd on the reference formulation."""
+    ph = pw = 16
+    h, w = F // ph, T // pw
+    L, P = h * w, ph * pw
+    g = torch.Generator().manual_seed(73)
+    imgs = torch.randn(B, 1, F, T, generator=g)
+    pred_full = torch.randn(B, row0 + L, P, generator=g, requires_grad=True)
+    mask = (torch.rand(B, L, generator=g) < 0.75).float()
+    xx = imgs.reshape(B, 1, h, ph, w, pw)
+    target = torch.einsum('nchpwq->nhwpqc', xx).reshape(B, L, P)
+    pred = pred_full[:, row0:]
+    loss = (((pred - target) ** 2).mean(dim=-1) * mask).sum() / mask.sum()
+    (3.0 * loss).backward()
+    acc2 = torch.empty(2, device=dev); out = torch.empty(1, device=dev)
+    pd = pred_full.detach().to(dev)
+    ops.mae_recon_loss_fwd(pd, row0, imgs.to(dev), mask.to(dev), ph, pw, acc2, out)
+    assert abs(float(out) - float(loss)) < 1e-5 * abs(float(loss))
+    assert float(acc2[1]) == float(mask.sum())
+    dpred = torch.full_like(pd, float("nan"))
+    ops.mae_recon_loss_bwd(pd, row0, imgs.to(dev), mask.to(dev), ph, pw, acc2, torch.tensor([3.0], device=dev), dpred)
+    assert rel_err(dpred, pred_full.grad.double()) < 1e-5
