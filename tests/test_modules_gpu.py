@@ -330,6 +330,49 @@ def test_log_mixup_exp_and_normalize_golden(dev, golden):
     assert np.abs(y.cpu().numpy() - g["nb_y"]).max() < 5e-6
 
 
+# ------------------------------------------------------------------------------------------------ main.py flow with local crops
+def test_main_py_local_crops_vs_oracle(dev, golden):
+    """main.py:86-119 with two 16x16 local crops: teacher = model(images[:1], ncrops=1), student = model(images[1:],
+    ncrops=L+1) -- MultiCropWrapper runs the 96-wide and the 16-wide group through the backbone separately (N = 25 and
+    N = 2 tokens, positional table interpolated to a 1x1 grid) -- and BarlowTwinsLoss(ncrops=L+2)(student, teacher,
+    ngcrops_each=1) averages L+1 terms.  Inputs: the reference's own AudioPairTransform output (golden); expected values:
+    the CPU oracle on the same weights (its pieces are golden-pinned one by one)."""
+    from oracle import step as ostep, heads as oheads, vit as ovit
+    ga, gs = golden("augment"), golden("step_plain")
+    L = int(ga["apt_seq96_local_L"])
+    views = ga["apt_seq96_local_views"]; locs = ga["apt_seq96_local_locals"]
+    imgs_np = [views[:, 0], views[:, 1]] + [locs[:, l] for l in range(L)]
+    cfg = hp.make_args(model_type="vit_tiny", projector_hidden_dim=192, projector_out_dim=64, batch_size=views.shape[0], local_crops_number=L)
+    net = utils.MultiCropWrapper(MicroBackbone(dev), model.BarlowTwinsHead(cfg, 128)).to(dev)
+    load_prefixed(net, gs, "online_sd.", dev)
+    crit = BarlowTwinsLoss(cfg, ncrops=L + 2).to(dev)
+    images = [T(x, dev) for x in imgs_np]
+    teacher = net(images[:1], ncrops=1)
+    student = net(images[1:], ncrops=L + 1)
+    loss = crit(student, teacher, ngcrops_each=1)
+    loss.backward()
+    # ---- oracle: same weights, CPU fp32 autograd
+    sd = {k[len("online_sd."):]: T(v) for k, v in gs.items() if k.startswith("online_sd.") and "num_batches" not in k}
+    names = [k for k in sd if ostep.is_param(k) and not any(f in k for f in ostep.FROZEN)]
+    leaf = dict(sd)
+    for k in names:
+        leaf[k] = sd[k].clone().requires_grad_(True)
+    cpu = [T(x) for x in imgs_np]
+    zt, _ = ostep.network_forward(leaf, cpu[:1], 1, 2, (4, 6))
+    zs, _ = ostep.network_forward(leaf, cpu[1:], L + 1, 2, (4, 6))
+    ref, _ = oheads.bt_forward(zs, zt, L + 2, ngcrops_each=1)
+    gref = torch.autograd.grad(ref, [leaf[k] for k in names], allow_unused=True)
+    assert rel(teacher, zt) < 2e-2 and rel(student, zs) < 2e-2          # bf16 GEMM operands through 2 blocks + projector
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 3e-2
+    named = dict(net.named_parameters())
+    errs = {k: rel(named[k].grad, gr) for k, gr in zip(names, gref) if gr is not None and float(gr.norm()) > 1e-3 and named[k].grad is not None}
+    # (norm.bias is excluded by the 1e-3 floor: the bias-free projector + BatchNorm cancel it, its true gradient is 1e-5 of the others)
+    assert len(errs) > 20
+    # B = 5 rows under BatchNorm + a correlation loss is as bf16-hostile as the step fixtures (see test_full_step_golden)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    assert sorted(errs.values())[len(errs) // 2] < 0.15 and max(errs.values()) < 0.5, worst
+
+
 # ------------------------------------------------------------------------------------------------ the trainer (bench path) vs the oracle
 def test_trainer_step_vs_oracle(dev):
     """Whole hot path: waveform -> log-mel -> views -> ViT-T + projector -> BT loss -> backward -> fused AdamW, against
