@@ -158,3 +158,33 @@ def test_host_side_pos_embed_and_sampling_match_oracle():
         g = e - min(e, 6) + r["bank_index"]
         slot = mix[r["view"] * 4 + (r["clip"] - 4)]
         assert slot == (g // 2) % 12 and src[r["view"] * 4 + (r["clip"] - 4)] == r["clip"] % 12
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """Error behaviour of the boundary: argument checks run first, return non-zero and leave a message naming the entry point
+    in sa_last_error -- no launch is attempted, so this runs on a CPU-only host."""
+    import ctypes as C
+    from ssl_audio_amd import _lib
+    h = _lib.lib()
+    P = C.c_void_p
+    null = P(0)
+    one = P(8)          # non-null, never dereferenced: every call below fails validation first
+    cases = {
+        "sa_layernorm_fwd": lambda: h.sa_layernorm_fwd(null, 0, null, null, null, null, 0, null, null, 4, 768, 1e-6, null),
+        "sa_layernorm_fwd(D)": lambda: h.sa_layernorm_fwd(one, 770, one, one, one, null, 770, null, null, 4, 770, 1e-6, null),
+        "sa_layernorm_bwd(ws)": lambda: h.sa_layernorm_bwd(one, 1, 768, one, 768, one, one, one, null, 0, one, null, 768, one, null, null, null, 4, 768, null),
+        "sa_attention_fwd": lambda: h.sa_attention_fwd(one, 8, 2304, 768, 12, 300, 0, 0.125, one, 768, null, null),
+        "sa_gather_rows": lambda: h.sa_gather_rows(one, 0, 0, one, 4, one, 0, 0, 2, 6, null),
+        "sa_mae_unshuffle_fwd": lambda: h.sa_mae_unshuffle_fwd(one, 9, one, one, one, 2, 8, 64, one, null),
+        "sa_mae_recon_loss_fwd": lambda: h.sa_mae_recon_loss_fwd(one, 10, 1, one, one, 2, 60, 96, 16, 16, one, one, null),
+        "sa_mean_tokens_fwd": lambda: h.sa_mean_tokens_fwd(one, 2, 1, 64, one, null),
+    }
+    for name, call in cases.items():
+        rc = call()
+        msg = h.sa_last_error().decode()
+        assert rc != 0, name
+        assert name.split("(")[0] in msg, (name, msg)
+    g = _lib.SaGemmArgs()
+    g.A, g.B, g.M, g.N, g.K, g.lda, g.ldb, g.split_k = 8, 8, 16, 16, 16, 12, 16, 1        # lda not a multiple of 8 elements
+    g.out_f32, g.ldo_f32, g.a_kmajor, g.b_kmajor, g.alpha = 8, 16, 1, 1, 1.0
+    assert h.sa_gemm_bf16(C.byref(g), null) != 0 and "sa_gemm_bf16" in h.sa_last_error().decode()
