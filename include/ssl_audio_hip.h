@@ -55,8 +55,13 @@ typedef struct SaGemmArgs {
                                    ADDED into out_f32 (caller zeroes / owns accumulation); only alpha is applied */
   int32_t accumulate;           /* split_k == 1 only: out_f32 += v instead of = v */
   int32_t tile256;              /* split_k > 1 only: use the 256 x 256 tile (one workgroup per CU) instead of 128 x 128 */
+  float* colsum_out;            /* optional [N]: += column sums of the fp32 epilogue result (the bias gradient of the Linear that
+                                   produced this GEMM's A operand's gradient, e.g. fc1's bias from the fc2 dgrad: utils of
+                                   models/mae.py:155 backward).  Needs split_k == 1, N % 64 == 0 and colsum_ws. */
+  float* colsum_ws;             /* scratch of sa_gemm_colsum_workspace_bytes(M, N) bytes */
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
+int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
 
 /* diagnostics only: cycle stamps of the persistent 256x256 kernel when SA_GEMM_DBG=8 (2 x 8 counters, see gemm_bf16.hip) */
 int sa_gemm_debug_counters(uint64_t* out16);

@@ -28,6 +28,7 @@ class SaGemmArgs(C.Structure):
         ("out_f32", P), ("ldo_f32", I64),
         ("out_bf16", P), ("ldo_bf16", I64),
         ("row_group", I32), ("split_k", I32), ("accumulate", I32), ("tile256", I32),
+        ("colsum_out", P), ("colsum_ws", P),
     ]
 
 
@@ -41,6 +42,7 @@ _SIGNATURES = {
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
     "sa_layernorm_bwd_workspace_bytes": [I32, I32],
     "sa_gemm_debug_counters": [P],
+    "sa_gemm_colsum_workspace_bytes": [I32, I32],
     "sa_mean_tokens_fwd": [P, I32, I32, I32, P, P],
     "sa_mean_tokens_bwd": [P, I32, I32, I32, P, P],
     "sa_mae_unshuffle_fwd": [P, I32, P, P, P, I32, I32, I32, P, P],

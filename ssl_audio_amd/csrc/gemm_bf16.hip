@@ -36,6 +36,7 @@ struct GemmParams {
   int split_k; int accumulate;
   int tiles_m, tiles_n;
   int gm;   // row-panels per tile group (L2 locality knob)
+  float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
 };
 
 // 16-byte-chunk XOR for a k-strided tile row: rows {0..3, 8..11} (one 32-lane half of a transposing
@@ -288,6 +289,26 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep each 16-row group's loads/stores together: hoisting all 16 residual loads spills
+  }
+  if (p.colsum_ws && m_base < p.M) {     // (a 64-row block wholly past M has no workspace row)
+    // column sums of this 64 x 64 block over its valid rows: 4 adds in registers, a 16-lane butterfly, one row of the workspace
+    float cs[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+        cs[j][r] = t;
+      }
+    if (c == 0) {
+      float* w = p.colsum_ws + (int64_t)(m_base >> 6) * p.N + n_base + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(w + j * 16) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+    }
   }
   if (p.out_bf16) staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
 }
@@ -1677,9 +1698,58 @@ extern "C" int sa_gemm_debug_counters(uint64_t* out16) {
   return 0;
 }
 
+namespace {
+// out[n] += sum over the rows of ws[rows][N]; 16 waves split the rows, lanes are columns
+__global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (col < N) {
+    const float* base = ws + col;
+    int r = wave;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)(r + u * 16) * N];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < rows; r += 16) acc += base[(int64_t)r * N];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    out[col] += t;
+  }
+}
+
+int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream);
+}  // namespace
+
+extern "C" int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)((M + 63) / 64) * N * (int64_t)sizeof(float); }
+
 extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SA_CHECK_ARG(a != nullptr, "sa_gemm_bf16: null args");
+  if (a->colsum_out) {
+    SA_CHECK_ARG(a->colsum_ws && a->split_k == 1 && a->N % 64 == 0, "sa_gemm_bf16: colsum_out needs colsum_ws, split_k == 1 and N %% 64 == 0");
+    SA_CHECK_ARG((!a->out_bf16 || (a->ldo_bf16 % 8 == 0 && ((uintptr_t)a->out_bf16 & 15) == 0)) &&
+                     (!a->aux_out || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux_out & 15) == 0)),
+                 "sa_gemm_bf16: colsum_out needs 16-byte aligned bf16 outputs with leading dimensions that are multiples of 8");
+  }
+  const int rc = gemm_dispatch(a, stream);
+  if (rc != 0 || !a->colsum_out) return rc;
+  hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3(a->N / 64), dim3(1024), 0, stream, a->colsum_ws, (a->M + 63) / 64, a->N, a->colsum_out);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(colsum reduce)");
+  return 0;
+}
+
+namespace {
+int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   SA_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "sa_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
   SA_CHECK_ARG(a->A && a->B, "sa_gemm_bf16: null operand");
   SA_CHECK_ARG(a->out_f32 || a->out_bf16, "sa_gemm_bf16: no output");
@@ -1716,6 +1786,7 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   p.out_f32 = a->out_f32; p.ldo_f32 = a->ldo_f32;
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
+  p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
   p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
   static const char* gm_env = getenv("SA_GEMM_GM");
   p.gm = gm_env ? atoi(gm_env) : 8;
@@ -1731,7 +1802,8 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   // forward + dgrad shapes: scripts/bench_gemm.py); small / ragged problems use the plain 128 x 128 kernel.
   // mode 8 (five-slot half-stage ring, requests trickled between MFMAs) measured 8-13 % faster than mode 6 on the dgrad (NN,
   // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
-  const char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
+  char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
+  if (mode == '2' && p.colsum_ws) mode = '6';   // the plain 256^2 kernel has its own epilogue without the column-sum hook
   if (mode == '8' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, false>(p, stream);
@@ -1804,6 +1876,7 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
     default: return launch<false, false, false>(p, stream);
   }
 }
+}  // namespace
 
 extern "C" int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   SA_CHECK_ARG(n >= 0 && (n == 0 || (src && dst)), "sa_cast_f32_to_bf16: bad args");

@@ -148,10 +148,12 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     if not b2_done:
         ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
-    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre)   # (dY W2) * GELU'(pre)
+    fuse_b1 = pre.shape[1] % 64 == 0                  # fc1's bias gradient = column sums of dpre: taken in the epilogue that produces it
+    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
     # fc1
     _wgrad(dpre, h2, g.w1)
-    ops.colsum_bf16(dpre, g.b1, accumulate=True)
+    if not fuse_b1:
+        ops.colsum_bf16(dpre, g.b1, accumulate=True)
     dh2 = torch.empty(M, d, dtype=BF16, device=dev)
     ops.gemm(dpre, W(p.w1), b_kmajor=False, out_bf16=dh2)
     del dpre

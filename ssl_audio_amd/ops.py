@@ -40,7 +40,7 @@ def _rows(t, name):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False, tile256=False):
+         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False, tile256=False, colsum_out=None):
     """D = epilogue(alpha * A.B).  A: [M,K] (a_kmajor) or [K,M]; B: [N,K] (b_kmajor, nn.Linear weight) or [K,N]."""
     _req(A, BF16, "A"), _req(B, BF16, "B")
     ar, ac, lda = _rows(A, "A")
@@ -67,6 +67,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     if out_bf16 is not None:
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
     a.row_group, a.split_k, a.accumulate, a.tile256 = row_group, split_k, int(accumulate), int(tile256)
+    if colsum_out is not None:          # colsum_out[n] += sum_m (fp32 epilogue result)[m][n], through a scratch of per-64-row partials
+        ws = torch.empty(lib().sa_gemm_colsum_workspace_bytes(M, N) // 4, dtype=F32, device=A.device)
+        a.colsum_out, a.colsum_ws = _req(colsum_out, F32, "colsum_out").data_ptr(), ws.data_ptr()
     if GEMM_PROFILE is None:
         check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
         return

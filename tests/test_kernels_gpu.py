@@ -119,6 +119,24 @@ def test_gemm_tile_modes(dev, env):
     assert r.returncode == 0 and "ok tile=" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (4000, 2112, 256)])
+def test_gemm_fused_column_sums(dev, M, N, K):
+    """colsum_out += column sums of the fp32 epilogue result (fc1's bias gradient taken in the fc2-dgrad epilogue), small
+    (128^2 kernel) and large (ring kernel, ragged last row tile) problems, NN layout with the GELU' epilogue."""
+    A = bf(rnd((M, K), 31)); W = bf(rnd((K, N), 32, 0.1)); pre = bf(rnd((M, N), 33))
+    acc = A.double() @ W.double()
+    hh = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(hh).sum().backward()
+    ref = acc * hh.grad
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    cs = torch.full((N,), 2.0, device=dev)
+    ops.gemm(A.to(dev), W.to(dev), b_kmajor=False, act=2, aux_in=pre.to(dev), out_bf16=out, colsum_out=cs)
+    assert rel_err(out, ref) < 4e-3
+    assert rel_err(cs, 2.0 + ref.sum(0)) < 1e-4
+    with pytest.raises(RuntimeError, match="colsum_out"):
+        ops.gemm(A.to(dev), W[:, :N - 8].contiguous().to(dev), b_kmajor=False, out_bf16=out[:, :N - 8], colsum_out=cs[:N - 8])
+
+
 def test_cast_and_colsum(dev):
     x = rnd((1000, 300), 10)
     y = ops.cast_bf16(x.to(dev))
