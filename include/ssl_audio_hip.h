@@ -63,6 +63,8 @@ typedef struct SaGemmArgs {
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
 
+/* diagnostics only: per-phase cycle stamps of one wave of sa_attention_bwd when SA_ATTN_DBG=8 (4 workgroups x 8 counters, see attention.hip) */
+int sa_attention_debug_counters(uint64_t* out32);
 /* diagnostics only: cycle stamps of the persistent 256x256 kernel when SA_GEMM_DBG=8 (2 x 8 counters, see gemm_bf16.hip) */
 int sa_gemm_debug_counters(uint64_t* out16);
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */

@@ -21,3 +21,13 @@ fw = t(lambda: ops.attention_fwd(qkv, H, N, 0.125, out, lse))
 bw = t(lambda: ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv))
 fl = 4.0 * S * H * N * N * 64
 print(f"attention fwd {fw:.1f} us ({fl/fw/1e6:.1f} TFLOP/s)   bwd {bw:.1f} us ({2.5*fl/bw/1e6:.1f} TFLOP/s algorithmic)")
+
+if os.environ.get("SA_ATTN_DBG") == "8":
+    import ctypes
+    from ssl_audio_amd._lib import lib
+    buf = (ctypes.c_uint64 * 32)()
+    assert lib().sa_attention_debug_counters(buf) == 0
+    names = ["stage issue + delta", "stage wait", "pass A", "barrier after A", "restage Q/dO", "pass B", "total"]
+    t00 = min(buf[w * 8 + 7] for w in range(4))
+    for w, wg in enumerate((100, 1100, 2100, 3000)):
+        print(f"attn_bwd wg {wg:4d} (start +{buf[w * 8 + 7] - t00:8d}): " + ", ".join(f"{n} {buf[w * 8 + i]}" for i, n in enumerate(names)))

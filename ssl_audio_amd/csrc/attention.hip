@@ -10,6 +10,7 @@
 // through ds_read_b64_tr_b16, so no transposed copy exists anywhere.
 // Backward recomputes P from the saved log-sum-exp: pass A (wave owns query tiles) produces dQ, pass B
 // (wave owns key tiles) produces dK and dV, so no gradient is ever summed across waves or workgroups.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
 
@@ -167,6 +168,11 @@ __global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* 
 }
 
 // =====================================================================================================
+__device__ unsigned long long sa_attn_prof[4][8];   // DBG & 8: cycle stamps of wave 3 of workgroups 100 / 1100 / 2100 / 3000: staging, pass A, restaging, pass B, total
+#define SA_ASTAMP() ((DBG & 8) ? __builtin_readcyclecounter() : 0ull)
+
+// DBG (SA_ATTN_DBG, timing experiments only, results wrong): 1 = one transposing read per 4 d-tiles, 2 = one row read per 2 k-steps, 4 = no exp
+template <int DBG = 0>
 __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
@@ -189,30 +195,44 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
   const int nkt = (N + 15) >> 4;
   const int nks = (N + 31) >> 5;
   const int nrows = nks * 32;
+  const unsigned long long t0 = SA_ASTAMP();
   stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
-  // delta[q] = sum_d dO[q][d] * O[q][d]  (straight from global, one query row per thread), lse -> LDS
+  // delta[q] = sum_d dO[q][d] * O[q][d], lse -> LDS.  Eight lanes share a query row (8 x 16 B = the row's 128 bytes of one head), so
+  // a wave instruction reads 8 whole row segments instead of 64 scattered 16-byte pieces (that version cost a quarter of the kernel).
   {
-    const int q = threadIdx.x;
-    float dl = 0.f, ls = INFINITY;                   // queries >= nq: lse = +inf makes every p exactly 0
-    if (q < nq && q < NMAX) {
-      const bf16x8* po = reinterpret_cast<const bf16x8*>(o + (row_base + q) * ldo + h * HD);
-      const bf16x8* pd = reinterpret_cast<const bf16x8*>(dout + (row_base + q) * ldo + h * HD);
+    const int sub = lane >> 3, ch = lane & 7;
+    constexpr int NIT = NMAX / (NW_BWD * 8);           // 4 row groups per wave: all 12 loads go out before the first is consumed
+    bf16x8 a[NIT], b[NIT];
+    float ls[NIT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bf16x8 a = po[i], b = pd[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dl += bf2f(a[j]) * bf2f(b[j]);
-      }
-      ls = lse[((int64_t)s * H + h) * N + q] * 1.44269504088896340736f;   // kept in log2 units for v_exp
+    for (int it = 0; it < NIT; ++it) {
+      const int q = (it * NW_BWD + wave) * 8 + sub;
+      const int qc = q < nq ? q : 0;                    // clamp: the row is read but its result discarded
+      a[it] = *reinterpret_cast<const bf16x8*>(o + (row_base + qc) * ldo + h * HD + ch * 8);
+      b[it] = *reinterpret_cast<const bf16x8*>(dout + (row_base + qc) * ldo + h * HD + ch * 8);
+      ls[it] = lse[((int64_t)s * H + h) * N + qc];
     }
-    if (q < NMAX) {
-      del_s[q] = dl;
-      lse_s[q] = ls;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = (it * NW_BWD + wave) * 8 + sub;
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += bf2f(a[it][j]) * bf2f(b[it][j]);
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      dl += __shfl_xor(dl, 4, 64);
+      if (ch == 0) {
+        del_s[q] = q < nq ? dl : 0.f;
+        // queries >= nq: lse = +inf makes every p exactly 0; kept in log2 units for v_exp
+        lse_s[q] = q < nq ? ls[it] * 1.44269504088896340736f : INFINITY;
+      }
     }
   }
+  const unsigned long long t0b = SA_ASTAMP();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  const unsigned long long t1 = SA_ASTAMP();
 
   const int g = lane >> 4, c = lane & 15;
   // per-lane LDS offsets, loop invariant: tile bases are multiples of 16 rows, so (row & 7) never depends on the tile
@@ -223,9 +243,9 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) trf[dt] = rr0 * 128 + ((((dt * 2) + (pp >> 1)) ^ (rr0 & 7)) << 4) + (pp & 1) * 8;
   }
-  auto RF = [&](const char* img, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(img + tile * 2048 + (ks ? rf1 : rf0)); };
+  auto RF = [&](const char* img, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(img + tile * 2048 + ((ks && !(DBG & 2)) ? rf1 : rf0)); };
   auto TR = [&](const char* img, int step, int dt) {
-    const char* b = img + step * 4096 + trf[dt];
+    const char* b = img + step * 4096 + trf[(DBG & 1) ? 0 : dt];
     s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
     s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 2048));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
         dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
+          const float p = ((DBG & 4) ? fmaf(sv[r], c2, -lq) : __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq)));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
           ds[u][r] = p * (dp[r] - dq_delta);                              // the softmax scale is applied once, to the accumulator
         }
       }
@@ -289,11 +309,14 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
   }
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
+  const unsigned long long t2 = SA_ASTAMP();
   __syncthreads();                                   // every wave is done reading the K / V images
+  const unsigned long long t2b = SA_ASTAMP();
   stage_rows(rs, Qimg, ld, h * HD, nqs * 32, wave, lane, NW_BWD);
   stage_rows(rd, Dimg, ldo, h * HD, nqs * 32, wave, lane, NW_BWD);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  const unsigned long long t3 = SA_ASTAMP();
   for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
@@ -319,7 +342,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
         const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r]));
+          const float p = ((DBG & 4) ? fmaf(sv[r], c2, -lq4[r]) : __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r])));
           pp[u][r] = p;
           ds[u][r] = p * (dp[r] - dq4[r]);
         }
@@ -343,9 +366,33 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
       }
     }
   }
+  if constexpr (DBG & 8) {
+    const int which = blockIdx.x == 100 ? 0 : blockIdx.x == 1100 ? 1 : blockIdx.x == 2100 ? 2 : blockIdx.x == 3000 ? 3 : -1;
+    if (which >= 0 && threadIdx.x == 64 * 3) {
+      const unsigned long long t4 = SA_ASTAMP();
+      unsigned long long* sa_attn_prof_w = sa_attn_prof[which];
+      sa_attn_prof_w[0] = t0b - t0;   // issue of the K/V staging + delta / lse prologue
+      sa_attn_prof_w[1] = t1 - t0b;   // wait for it
+      sa_attn_prof_w[2] = t2 - t1;    // pass A (this wave)
+      sa_attn_prof_w[3] = t2b - t2;   // barrier after pass A (slowest wave)
+      sa_attn_prof_w[4] = t3 - t2b;   // Q / dO restaging
+      sa_attn_prof_w[5] = t4 - t3;    // pass B (this wave)
+      sa_attn_prof_w[6] = t4 - t0;    // total
+      sa_attn_prof_w[7] = t0;         // start stamp
+    }
+  }
 }
 
 }  // namespace
+
+extern "C" int sa_attention_debug_counters(uint64_t* out8 /* 4 x 8 */) {
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpyFromSymbol(out8, HIP_SYMBOL(sa_attn_prof), 32 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    sa_set_error("sa_attention_debug_counters: copy failed");
+    return 2;
+  }
+  return 0;
+}
 
 static int attn_check(const char* who, const void* qkv, int64_t rows, int64_t ld, int C, int H, int N) {
   SA_CHECK_ARG(qkv && rows > 0, "%s: null/empty input", who);
@@ -380,14 +427,28 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
   if (attn_check("sa_attention_bwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && dout && lse && dqkv && ldo >= C && ldo % 8 == 0, "sa_attention_bwd: bad args");
   SA_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)out & 15) == 0, "sa_attention_bwd: out/dout must be 16-byte aligned");
-  const int lds = 2 * IMG + 2 * NMAX * (int)sizeof(float);
+  static const char* pad = getenv("SA_ATTN_LDS_PAD");          // experiment: extra LDS bytes per workgroup (occupancy probe)
+  const int lds = 2 * IMG + 2 * NMAX * (int)sizeof(float) + (pad ? atoi(pad) : 0);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     configured = true;
   }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query, scale,
+  static const char* dbg = getenv("SA_ATTN_DBG");
+  if (dbg && atoi(dbg) > 0) {
+#define SA_ATTN_CASE(D)                                                                                                                      \
+  case D:                                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);           \
+    hipLaunchKernelGGL(attn_bwd_kernel<D>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, \
+                       N, n_query, scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);                             \
+    break;
+    switch (atoi(dbg)) { SA_ATTN_CASE(1) SA_ATTN_CASE(2) SA_ATTN_CASE(3) SA_ATTN_CASE(4) SA_ATTN_CASE(7) SA_ATTN_CASE(8) default: break; }
+#undef SA_ATTN_CASE
+    SA_LAUNCH_CHECK("sa_attention_bwd(dbg)");
+    return 0;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query, scale,
                      (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   SA_LAUNCH_CHECK("sa_attention_bwd");
   return 0;
