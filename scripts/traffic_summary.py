@@ -1,17 +1,40 @@
+"""HBM bytes per GEMM launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KiB units; FETCH doubled per the gfx950 note in
+MI355X_MICROARCH.md), overall and per device kernel (same family names as ops.gemm_kernel_family / bench.py's roofline object)."""
 import csv, glob, json, sys, collections
 root, out = sys.argv[1], sys.argv[2]
-tot = collections.defaultdict(lambda: [0.0, 0])
+
+
+def family(name):
+    if "colsum" in name or "gemm" not in name:
+        return None
+    if "gemm256_persist_kernel" in name: return "gemm256_persist_kernel"
+    if "gemm256_ring_kernel" in name: return "gemm256_ring_kernel<split-K>" if "true>(" in name.split("gemm256_ring_kernel")[1][:24].replace(" ", "").split(",")[-1] else "gemm256_ring_kernel"
+    if "gemm256_kernel" in name: return "gemm256_kernel<split-K>"
+    if "gemm_kernel" in name: return "gemm_kernel<split-K>" if name.split("gemm_kernel<")[1].split(">")[0].replace(" ", "").endswith("false") else "gemm_kernel"
+    return "other"
+
+
+tot = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm" in r["Kernel_Name"] and "colsum" not in r["Kernel_Name"]:
-            t = tot[r["Counter_Name"]]
+        fam = family(r["Kernel_Name"])
+        if fam is None:
+            continue
+        for key in (fam, "__all__"):
+            t = tot[key][r["Counter_Name"]]
             t[0] += float(r["Counter_Value"]); t[1] += 1
-fetch_kb, nf = tot["FETCH_SIZE"]; write_kb, nw = tot["WRITE_SIZE"]
-res = {"launches_fetch": nf, "launches_write": nw,
-       "fetch_bytes_per_launch_raw": fetch_kb * 1024 / max(nf, 1),
-       "fetch_bytes_per_launch_corrected_x2": 2 * fetch_kb * 1024 / max(nf, 1),
-       "write_bytes_per_launch": write_kb * 1024 / max(nw, 1),
-       "hbm_bytes_per_launch": (2 * fetch_kb / max(nf, 1) + write_kb / max(nw, 1)) * 1024,
-       "note": "all sa_gemm_bf16 launches of `bench.py --steps 2 --warmup 1` (3 steps); FETCH_SIZE doubled per the gfx950 correction"}
+
+
+def summarise(d):
+    fetch_kb, nf = d["FETCH_SIZE"]; write_kb, nw = d["WRITE_SIZE"]
+    return {"launches": nf, "fetch_bytes_per_launch_raw": fetch_kb * 1024 / max(nf, 1),
+            "fetch_bytes_per_launch_corrected_x2": 2 * fetch_kb * 1024 / max(nf, 1),
+            "write_bytes_per_launch": write_kb * 1024 / max(nw, 1),
+            "hbm_bytes_per_launch": (2 * fetch_kb / max(nf, 1) + write_kb / max(nw, 1)) * 1024}
+
+
+res = summarise(tot["__all__"])
+res["per_kernel"] = {k: summarise(v) for k, v in tot.items() if k != "__all__"}
+res["note"] = "sa_gemm_bf16 launches of `bench.py --steps 2 --warmup 1` (3 steps); FETCH_SIZE doubled per the gfx950 correction"
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res))
+print(json.dumps({k: (v if k != "per_kernel" else {n: round(x["hbm_bytes_per_launch"] / 1e6, 1) for n, x in v.items()}) for k, v in res.items()}))

@@ -79,9 +79,21 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
     e1.record()
     kind = ("NT" if b_kmajor else "NN") if a_kmajor else ("TT" if b_kmajor else "TN")
+    kname = gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256)
     nbytes = 2.0 * (M * K + N * K) + (4.0 * M * N if out_f32 is not None else 0.0) + (2.0 * M * N if out_bf16 is not None else 0.0) \
         + (2.0 * M * N if (aux_in is not None or aux_out is not None) else 0.0) + (4.0 * M * N if residual is not None and not res_mod else 0.0)
-    GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes))
+    GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes, kname))
+
+
+def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256):
+    """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
+    override); used to label bench.py's per-launch timings with the names rocprofv3 reports."""
+    if split_k > 1:
+        return "gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>"
+    big = M >= 1024 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
+    if not big:
+        return "gemm_kernel"
+    return "gemm256_ring_kernel" if (a_kmajor and not b_kmajor) else "gemm256_persist_kernel"
 
 
 def pick_split_k(M, N, K, cu_count=256, tile=128):
