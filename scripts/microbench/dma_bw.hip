@@ -15,7 +15,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // RB = bytes per row per stage (128 or 64); DEPTH = stages in flight; NW waves
-template <int RB, int DEPTH, int NW>
+template <int RB, int DEPTH, int NW, bool CONTIG = false>
 __global__ __launch_bounds__(64 * NW) void dma_kernel(const char* A, uint32_t a_bytes, int lda_b, const char* B, uint32_t b_bytes, int ldb_b,
                                                       int tiles_m, int tiles_n, int ksteps, float* sink, int GM, int GN, int reps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,8 +48,15 @@ __global__ __launch_bounds__(64 * NW) void dma_kernel(const char* A, uint32_t a_
       const int q = wave * PER_WAVE + i;       // 0 .. INSTR-1; first half A, second half B
       const int row = (q % (INSTR / 2)) * RPI + lane / LPR;
       const uint32_t col = (uint32_t)kt * RB + (lane % LPR) * 16;
+      if constexpr (CONTIG) {
+        // pre-tiled operand: the K-tile of a 256-row panel is one contiguous 32 KiB block, instruction q reads 1 KiB of it
+        const uint32_t hq = q % (INSTR / 2);
+        if (q < INSTR / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(buf + q * 1024), 16, ((uint32_t)(m0 / 256) * ksteps + kt) * (256u * RB) + hq * 1024 + lane * 16, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(buf + q * 1024), 16, ((uint32_t)(n0 / 256) * ksteps + kt) * (256u * RB) + hq * 1024 + lane * 16, 0, 0, 0);
+      } else {
       if (q < INSTR / 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(buf + q * 1024), 16, (uint32_t)(m0 + row) * lda_b + col, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(buf + q * 1024), 16, (uint32_t)(n0 + row) * ldb_b + col, 0, 0, 0);
+      }
     }
   };
   int g = 0;
@@ -277,18 +284,18 @@ void run_mix(const char* A, size_t a_bytes, int lda_b, const char* B, size_t b_b
          bytes / (ms * 1e-3) / 256 / 2.4e9, err == hipSuccess ? "ok" : hipGetErrorString(err));
 }
 
-template <int RB, int DEPTH, int NW>
+template <int RB, int DEPTH, int NW, bool CONTIG = false>
 void run(const char* name, const char* A, size_t a_bytes, int lda_b, const char* B, size_t b_bytes, int ldb_b, int M, int N, int Kbytes, float* sink, int grid, int GM, int GN, int reps = 1) {
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, ksteps = Kbytes / RB;
   const int lds = DEPTH * 512 * RB;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(dma_kernel<RB, DEPTH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dma_kernel<RB, DEPTH, NW, CONTIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w)
-    hipLaunchKernelGGL((dma_kernel<RB, DEPTH, NW>), dim3(grid), dim3(64 * NW), lds, 0, A, (uint32_t)a_bytes, lda_b, B, (uint32_t)b_bytes, ldb_b, tiles_m, tiles_n, ksteps, sink, GM, GN, reps);
+    hipLaunchKernelGGL((dma_kernel<RB, DEPTH, NW, CONTIG>), dim3(grid), dim3(64 * NW), lds, 0, A, (uint32_t)a_bytes, lda_b, B, (uint32_t)b_bytes, ldb_b, tiles_m, tiles_n, ksteps, sink, GM, GN, reps);
   hipEventRecord(e0);
   const int nrep = 5;
   for (int w = 0; w < nrep; ++w)
-    hipLaunchKernelGGL((dma_kernel<RB, DEPTH, NW>), dim3(grid), dim3(64 * NW), lds, 0, A, (uint32_t)a_bytes, lda_b, B, (uint32_t)b_bytes, ldb_b, tiles_m, tiles_n, ksteps, sink, GM, GN, reps);
+    hipLaunchKernelGGL((dma_kernel<RB, DEPTH, NW, CONTIG>), dim3(grid), dim3(64 * NW), lds, 0, A, (uint32_t)a_bytes, lda_b, B, (uint32_t)b_bytes, ldb_b, tiles_m, tiles_n, ksteps, sink, GM, GN, reps);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= nrep;
   hipError_t err = hipGetLastError();
@@ -303,19 +310,14 @@ int main() {
   for (int cfg = 0; cfg < 2; ++cfg) {
     const int M = Ms[cfg], K = Ks[cfg], N = Ns[cfg];
     const int ld_b = K * 2;
-    const size_t a_bytes = (size_t)M * ld_b, b_bytes = (size_t)N * ld_b;
+    const size_t a_bytes = (size_t)(M + 256) * ld_b, b_bytes = (size_t)N * ld_b;
     char *A, *B; hipMalloc(&A, a_bytes + 65536); hipMalloc(&B, b_bytes + 65536);
     hipMemset(A, 1, a_bytes); hipMemset(B, 1, b_bytes);
     printf("---- M=%d N=%d K=%d\n", M, N, K);
-    run<128, 1, 8>("lds-dma d1", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
-    run<128, 2, 8>("lds-dma d2", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
-    run_mix<true>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_mix<false>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_reg<1, false>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_reg<2, false>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_reg<3, false>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_reg<1, true>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
-    run_reg<2, true>(A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink);
+    run<128, 1, 8>("row-major d1", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
+    run<128, 2, 8>("row-major d2", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
+    run<128, 1, 8, true>("pre-tiled d1", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
+    run<128, 2, 8, true>("pre-tiled d2", A, a_bytes, ld_b, B, b_bytes, ld_b, M, N, K * 2, sink, 256, 4, N / 256, 1);
     hipFree(A); hipFree(B);
   }
   return 0;

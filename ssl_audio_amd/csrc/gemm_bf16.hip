@@ -71,23 +71,8 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   }
 }
 
-// one wave-instruction (number q of 16) of stage_tile: lets a kernel space its LDS-DMA requests out between MFMAs
-template <bool KMAJOR>
-__device__ __forceinline__ void stage_one(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane) {
-  uint32_t voff;
-  if constexpr (KMAJOR) {
-    const int row = q * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (row & 7);
-    voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
-  } else {
-    const int krow = q * 4 + (lane >> 4);
-    const int chunk = (lane & 15) ^ ks_swz(krow);
-    voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
-  }
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
-}
-
-// stage_one with a validity flag: an invalid request goes out of range (zero fill, no traffic) so vmcnt bookkeeping stays exact
+// one wave-instruction (number q of 16) of stage_tile, with a validity flag: lets a kernel space its LDS-DMA requests out between
+// MFMAs; an invalid request goes out of range (zero fill, no traffic) so vmcnt bookkeeping stays exact
 template <bool KMAJOR>
 __device__ __forceinline__ void stage_one_v(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane, bool valid) {
   uint32_t voff;
@@ -1014,19 +999,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
   auto stage_all = [&](char* buf, int m0, int n0, int k0) {
-    if constexpr (DBG & 32) {          // one wave per SIMD (waves 0..3) issues all the LDS-DMA; its SIMD partner never blocks on the memory pipe
-      if (wave < 4) {
-        stage_tile<A_KM, 4>(ra, buf, p.lda, m0, k0, wave, lane);
-        stage_tile<A_KM, 4>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
-        stage_tile<B_KM, 4>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
-        stage_tile<B_KM, 4>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
-      }
-    } else {
-      stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
-      stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
-      stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
-      stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
-    }
+    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
+    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
   };
 
   int t = lid;
@@ -1056,22 +1032,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
     for (int kt = 0; kt < ksteps; ++kt) {
       const bool more = kt + 1 < ksteps;
-      if constexpr (!(DBG & 16)) {
-        if (!(DBG & 1) || kt == 0) {
-          if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
-          else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
-        }
+      if (!(DBG & 1) || kt == 0) {
+        if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
+        else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
       }
-      // DBG & 16: the eight LDS-DMA requests of this wave are issued one at a time between the MFMAs of the first two quadrants
-      const bool dma_on = more || has_next;
-      const int dm0 = more ? m0 : m0n, dn0 = more ? n0 : n0n, dk0 = more ? (kt + 1) * BK : 0;
-      auto dma_piece = [&](int j) {
-        if (!dma_on) return;
-        char* buf = smem + (cur ^ 1) * BUF + (j >> 1) * TILE_BYTES;
-        const int q = wave * 2 + (j & 1);
-        if (j < 4) stage_one<A_KM>(ra, buf, p.lda, dm0 + (j >> 1) * 128, dk0, q, lane);
-        else stage_one<B_KM>(rb, buf, p.ldb, dn0 + ((j >> 1) - 2) * 128, dk0, q, lane);
-      };
       const char* ta = smem + cur * BUF + wr * TILE_BYTES;
       const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
       const int bcol = (wc & 1) * 64;
@@ -1089,10 +1053,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[i][j]);
-            if constexpr ((DBG & 16) != 0) if (j == 1 && (i & 1)) dma_piece(ks * 2 + (i >> 1));
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[i][j]);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1102,10 +1063,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[i][2 + j]);
-            if constexpr ((DBG & 16) != 0) if (j == 1 && (i & 1)) dma_piece(4 + ks * 2 + (i >> 1));
-          }
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[i][2 + j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1189,7 +1147,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                                 \
     hipLaunchKernelGGL((gemm256_persist_kernel<true, true, D>), g, b, 8 * TILE_BYTES, stream, p);                           \
     break;
-      switch (atoi(dbg)) { SA_DBG_CASE(1) SA_DBG_CASE(2) SA_DBG_CASE(3) SA_DBG_CASE(4) SA_DBG_CASE(5) SA_DBG_CASE(6) SA_DBG_CASE(7) SA_DBG_CASE(8) SA_DBG_CASE(16) SA_DBG_CASE(24) SA_DBG_CASE(32) SA_DBG_CASE(40) }
+      switch (atoi(dbg)) { SA_DBG_CASE(1) SA_DBG_CASE(2) SA_DBG_CASE(3) SA_DBG_CASE(4) SA_DBG_CASE(5) SA_DBG_CASE(6) SA_DBG_CASE(7) SA_DBG_CASE(8) }
 #undef SA_DBG_CASE
       SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, dbg)");
       return 0;
@@ -1615,6 +1573,182 @@ int launch256_ring(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
+
+// =====================================================================================================
+// Persistent 256 x 256 x 64 kernel with EARLY operand requests ("mode 9").
+// Finding: the K-loop runs at the round-trip time of one 64 KiB LDS-DMA stage (~2900 cycles), not at the MFMA
+// floor (2048), because with two LDS buffers a stage can only be requested when the step that reads its buffer has ended.
+// But a step's LAST LDS read (the second half of the A fragments) happens before quadrants Q2/Q3 issue: a second barrier
+// there proves the buffer dead half a step early, so the request for the K-tile after next goes out then -- 1.5 steps of
+// lead and up to two stages in flight, with no extra LDS or registers.  The eight requests are trickled between the
+// MFMAs of Q2/Q3; the end-of-step wait is vmcnt(8) (those eight stay in flight; older stores cannot fool the count because
+// loads retire in order).  On a tile's last step the request is deferred past the epilogue, which borrows that buffer.
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(512, 2) void gemm256_early_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A half0 | A half1 | B half0 | B half1]
+  constexpr int BUF = 4 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  auto coords = [&](int t, int& m0, int& n0) {
+    const int grp = t / group_sz, within = t - grp * group_sz;
+    const int gm = min(GM, p.tiles_m - grp * GM);
+    m0 = (grp * GM + within % gm) * 256;
+    n0 = (within / gm) * 256;
+  };
+  const int ksteps = (p.K + BK - 1) / BK;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+  int t = lid;
+  if (t >= ntiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+
+  struct StageReq { int m0, n0, k0, valid; };
+  int rt = t, rm0 = m0, rn0 = n0, rk = 0;              // request cursor over this workgroup's K-tile stream
+  auto next_stage = [&]() {
+    StageReq q = {rm0, rn0, rk * BK, rt < ntiles};
+    if (q.valid && ++rk == ksteps) {
+      rk = 0;
+      rt += nwg;
+      if (rt < ntiles) coords(rt, rm0, rn0);
+    }
+    return q;
+  };
+  auto piece = [&](const StageReq& q, char* buf, int j) {   // this wave's request j (0..7) of a stage: tile j >> 1, instruction j & 1
+    const int tile = j >> 1, ins = wave * 2 + (j & 1);
+    if (tile < 2) stage_one_v<A_KM>(ra, buf + tile * TILE_BYTES, p.lda, q.m0 + tile * 128, q.k0, ins, lane, q.valid);
+    else stage_one_v<B_KM>(rb, buf + tile * TILE_BYTES, p.ldb, q.n0 + (tile - 2) * 128, q.k0, ins, lane, q.valid);
+  };
+  {
+    const StageReq q0 = next_stage();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(q0, smem, j);
+    const StageReq q1 = next_stage();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(q1, smem + BUF, j);
+  }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  const int bcol = (wc & 1) * 64;
+
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ksteps; ++kt) {
+      const bool last = kt + 1 == ksteps;
+      char* bufc = smem + cur * BUF;
+      const char* ta = bufc + wr * TILE_BYTES;
+      const char* tb = bufc + (2 + (wc >> 1)) * TILE_BYTES;
+      bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+      // ---- mid-step barrier: every wave has made its last read of this buffer -> it can be refilled half a step early
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      StageReq rq = {0, 0, 0, 0};
+      const bool pending = !last;                       // a tile's last step leaves the buffer to the epilogue
+      if (pending) rq = next_stage();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
+            if (j == 1 && (i & 1) && pending) piece(rq, bufc, ks * 2 + (i >> 1));
+          }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+            if (j == 1 && (i & 1) && pending) piece(rq, bufc, 4 + ks * 2 + (i >> 1));
+          }
+      // ---- end of step: the OTHER buffer (requested 1.5 steps ago) must have landed; this step's own requests stay in flight
+      if (pending) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur ^= 1;
+    }
+    char* wl = smem + (cur ^ 1) * BUF + wave * 8192;     // the buffer of the last step: no request was sent into it
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    t += nwg;
+    if (t >= ntiles) break;
+    coords(t, m0, n0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // all epilogue scratch reads done
+    const StageReq rq = next_stage();                    // the request the last step deferred
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piece(rq, smem + (cur ^ 1) * BUF, j);
+  }
+}
+
+template <bool A_KM, bool B_KM>
+int launch256_early(GemmParams p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: cannot query the device");
+      return 2;
+    }
+    slots = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_early_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              8 * TILE_BYTES);
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((gemm256_early_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256 early)");
+  return 0;
+}
+
 template <bool A_KM, bool B_KM, bool SWAP>
 int launch(const GemmParams& p, hipStream_t stream) {
   const int nwg = p.tiles_m * p.tiles_n * p.split_k;
@@ -1804,6 +1938,13 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
   char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
   if (mode == '2' && p.colsum_ws) mode = '6';   // the plain 256^2 kernel has its own epilogue without the column-sum hook
+  if (mode == '9' && a->split_k == 1) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    if (a->a_kmajor && a->b_kmajor) return launch256_early<true, true>(p, stream);
+    if (a->a_kmajor && !a->b_kmajor) return launch256_early<true, false>(p, stream);
+    if (!a->a_kmajor && a->b_kmajor) return launch256_early<false, true>(p, stream);
+    return launch256_early<false, false>(p, stream);
+  }
   if (mode == '8' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, false>(p, stream);
