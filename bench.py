@@ -91,6 +91,12 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator comes up, so
+    # the process-level stdout is parked on stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from ssl_audio_amd import dist as sdist, hyperparameters as hp, ops
     from ssl_audio_amd.selfcheck import synthetic_waveforms
     from ssl_audio_amd.train import BarlowTwinsTrainer
@@ -202,8 +208,10 @@ def main():
             note("timing the CPU baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline(args.workload)
             note("CPU baseline done")
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

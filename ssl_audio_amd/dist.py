@@ -46,10 +46,16 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def collectives_active():
+    """True when the exchanges must really be issued: more than one rank, or SA_DIST_FORCE=1 under an initialised process
+    group (a one-rank RCCL rehearsal of every collective call site on a single GPU; results are unchanged)."""
+    return get_world_size() > 1 or (os.environ.get("SA_DIST_FORCE") == "1" and is_dist_avail_and_initialized())
+
+
 def all_gather_rows(t):
     """[*shape] -> [W, *shape] (W = 1 without a process group: a view, no copy)."""
     W = get_world_size()
-    if W == 1:
+    if not collectives_active():
         return t.unsqueeze(0)
     flat = t.contiguous().view(-1)
     out = torch.empty(W * flat.numel(), dtype=t.dtype, device=t.device)      # 1-D in / 1-D out: accepted by RCCL and gloo alike
@@ -58,6 +64,6 @@ def all_gather_rows(t):
 
 
 def all_reduce_sum_(t):
-    if get_world_size() > 1:
+    if collectives_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

@@ -103,14 +103,15 @@ class GradSync:
     def __init__(self, flat, bucket_bytes=64 << 20):
         self.flat = flat
         self.world = sdist.get_world_size()
-        self.stream = torch.cuda.Stream() if (self.world > 1 and flat.grads.is_cuda) else None
+        self.active = sdist.collectives_active()
+        self.stream = torch.cuda.Stream() if (self.active and flat.grads.is_cuda) else None
         self.pending = []
         self.bucket_bytes = bucket_bytes
         self._ready_ranges = []
 
     def block_done(self, params):
         """engine.BLOCK_DONE_HOOK: the gradients of `params` are final -> reduce their flat range now."""
-        if self.world == 1:
+        if not self.active:
             return
         spans = []
         for p in params:
@@ -148,7 +149,7 @@ class GradSync:
 
     def finish(self):
         """Reduce whatever no block hook covered (head, cls token, final norm, ...) and join the side stream."""
-        if self.world == 1:
+        if not self.active:
             return
         n = self.flat.n_train
         gaps, cur = [], 0

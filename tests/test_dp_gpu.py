@@ -104,3 +104,23 @@ def test_two_ranks_equal_single_process():
                 frac_same = np.mean(np.abs(r[2][k] - ref) <= 0.25 * lr)
                 assert frac_same > 0.7, (k, frac_same)        # Adam turns near-zero gradients into +-lr: sign flips are expected
         np.testing.assert_array_equal(res[0][2][k], res[1][2][k])        # replicas stay bit-identical across ranks
+
+
+def test_rccl_call_sites_with_one_rank():
+    """The driver's multi-GPU launch (`torch.distributed.run ... bench.py --gpus N`, backend nccl = RCCL) rehearsed with one
+    rank: SA_DIST_FORCE=1 makes every collective call site really issue its RCCL call (all-gather of BN statistics, all-reduce
+    of the cross-correlation / BN backward sums, per-block gradient all-reduce on the side stream).  With one rank the sums are
+    identities, so the loss must equal the plain run's -- and stdout must be exactly one JSON line (RCCL prints a banner)."""
+    import json, subprocess
+    common = ["bench.py", "--workload", "vit_tiny_bt_10s", "--batch_per_gpu", "8", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"]
+    plain = subprocess.run([sys.executable] + common, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env = dict(os.environ, SA_DIST_FORCE="1")
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(_free_port())] + common + ["--gpus", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert dist.returncode == 0, dist.stderr[-2000:]
+    lines = [l for l in dist.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, dist.stdout[:2000]
+    a, b = json.loads(plain.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    assert b["n_gpus"] == 1 and b["config"]["parallelism"] == "dp1"
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"])
