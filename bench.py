@@ -204,7 +204,7 @@ def main():
                                       "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0}},
                          "whole_step_tflops": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only (rank 0 is the only rank)
             note("timing the CPU baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline(args.workload)
             note("CPU baseline done")
