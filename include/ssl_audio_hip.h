@@ -136,6 +136,12 @@ int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_
 int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream);
 int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream);
+/* LARS on one parameter tensor (utils/utils.py:150-189, selected by `--optimizer LARS`, main_bt_byol.py:326-345):
+ * dp = g + weight_decay * p (pass 0 where the reference's weight_decay_filter excludes the tensor);
+ * lars_adaptation != 0: dp *= eta * |p| / |dp| (1 when either norm is 0); mu = momentum * mu + dp; p -= lr * mu.
+ * scratch2: 2 floats (squared norms), required with lars_adaptation; p_bf16 (optional): refreshed bf16 copy. */
+int sa_lars_step(float* p, const float* g, float* mu, int64_t n, float lr, float weight_decay, float momentum, float eta,
+                 int32_t lars_adaptation, float* scratch2, void* p_bf16, void* stream);
 /* y += a * x on flat fp32 buffers (gradient accumulation of small vectors) */
 int sa_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);
 

@@ -70,6 +70,22 @@ class AdamW:
                 p.addcdiv_(self.m[n], denom, value=-self.lr / c1)
 
 
+def lars_step(p, g, mu, lr, weight_decay, momentum=0.9, eta=0.001, weight_decay_filter=False, lars_adaptation_filter=False):
+    """One LARS update of one tensor, restated from utils/utils.py:161-189 (returns new p, mu; torch CPU fp32):
+    dp = g (+ wd p unless the filter excludes 1-D tensors); trust ratio q = eta |p| / |dp| when both norms are positive, else 1
+    (skipped for 1-D tensors under lars_adaptation_filter); mu <- momentum mu + q dp; p <- p - lr mu."""
+    one_d = p.dim() == 1
+    dp = g.clone()
+    if not (weight_decay_filter and one_d):
+        dp = dp + weight_decay * p
+    if not (lars_adaptation_filter and one_d):
+        pn, un = float(torch.linalg.vector_norm(p)), float(torch.linalg.vector_norm(dp))
+        q = eta * pn / un if (pn > 0.0 and un > 0.0) else 1.0
+        dp = dp * q
+    mu = mu * momentum + dp
+    return p - lr * mu, mu
+
+
 def ema_update(target, online, beta, param_names):
     """update_moving_average (utils/utils.py:328-331): parameters only, buffers untouched."""
     with torch.no_grad():

@@ -200,6 +200,43 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
 
+// ---- LARS (utils/utils.py:150-189): dp = g (+ wd * p); q = eta * |p| / |dp| (1 if either norm is 0); mu = momentum * mu + q * dp;
+// p -= lr * mu.  Pass 1: the two squared norms into scratch[0..1]; pass 2: the update (also refreshes the bf16 weight copy).
+__global__ __launch_bounds__(256) void lars_norms_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n, float wd,
+                                                         float* __restrict__ scratch) {
+  __shared__ float red[8];
+  float sp = 0.f, su = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i], di = g[i] + wd * pi;
+    sp += pi * pi;
+    su += di * di;
+  }
+  sp = block_sum_256(sp, red);
+  su = block_sum_256(su, red + 4);
+  if (threadIdx.x == 0) {
+    atomicAdd(scratch + 0, sp);
+    atomicAdd(scratch + 1, su);
+  }
+}
+
+__global__ void lars_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu, int64_t n, float lr, float wd,
+                                   float momentum, float eta, int adapt, const float* __restrict__ scratch, bf16_t* __restrict__ p_bf16) {
+  float q = 1.f;
+  if (adapt) {
+    const float pn = sqrtf(scratch[0]), un = sqrtf(scratch[1]);
+    q = (pn > 0.f && un > 0.f) ? eta * pn / un : 1.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float di = (g[i] + wd * pi) * q;
+    const float mi = mu[i] * momentum + di;
+    const float po = pi - lr * mi;
+    mu[i] = mi;
+    p[i] = po;
+    if (p_bf16) p_bf16[i] = f2bf(po);
+  }
+}
+
 inline int flat_grid(int64_t n, int per_thread = 1) {
   const int64_t want = (n + 256LL * per_thread - 1) / (256LL * per_thread);
   return (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
@@ -309,5 +346,22 @@ extern "C" int sa_axpy_f32(float* y, const float* x, int64_t n, float a, void* s
   if (n == 0) return 0;
   hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, y, x, n, a);
   SA_LAUNCH_CHECK("sa_axpy_f32");
+  return 0;
+}
+
+extern "C" int sa_lars_step(float* p, const float* g, float* mu, int64_t n, float lr, float weight_decay, float momentum, float eta,
+                            int32_t lars_adaptation, float* scratch2, void* p_bf16, void* stream) {
+  SA_CHECK_ARG(p && g && mu && n >= 0 && (!lars_adaptation || scratch2), "sa_lars_step: bad args (the trust ratio needs a 2-float scratch)");
+  if (n == 0) return 0;
+  if (lars_adaptation) {
+    if (hipMemsetAsync(scratch2, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      sa_set_error("sa_lars_step: memset failed");
+      return 2;
+    }
+    hipLaunchKernelGGL(lars_norms_kernel, dim3(flat_grid(n, 8)), dim3(256), 0, (hipStream_t)stream, p, g, n, weight_decay, scratch2);
+  }
+  hipLaunchKernelGGL(lars_update_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, mu, n, lr, weight_decay, momentum, eta,
+                     lars_adaptation, scratch2, (bf16_t*)p_bf16);
+  SA_LAUNCH_CHECK("sa_lars_step");
   return 0;
 }

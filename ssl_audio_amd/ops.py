@@ -231,6 +231,11 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf
                               float(grad_scale), _p(p_bf16), _stream()), "sa_adamw_step")
 
 
+def lars_step(p, g, mu, lr, wd, momentum, eta, adapt, scratch2=None, p_bf16=None):
+    check(lib().sa_lars_step(_p(_req(p, F32, "p")), _p(_req(g, F32, "g")), _p(_req(mu, F32, "mu")), p.numel(), float(lr), float(wd), float(momentum),
+                             float(eta), int(bool(adapt)), _p(scratch2), _p(p_bf16), _stream()), "sa_lars_step")
+
+
 def ema_update(target, online, beta):
     check(lib().sa_ema_update(_p(target), _p(online), target.numel(), float(beta), _stream()), "sa_ema_update")
 

@@ -96,3 +96,82 @@ def model_setup_ddp(gpu, model):
 def save_on_master(*args, **kwargs):
     if is_main_process():
         torch.save(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser family
+class LARS(torch.optim.Optimizer):
+    """`utils.LARS` (utils/utils.py:150-189; `--optimizer LARS`, main_bt_byol.py:326-345): SGD with momentum on
+    dp = g + wd * p, rescaled per tensor by the trust ratio eta * |p| / |dp|.  Same constructor and group keys; the
+    arithmetic is two HIP launches per tensor (`sa_lars_step`).  1-D tensors skip decay / adaptation when the filters ask."""
+
+    def __init__(self, params, lr, weight_decay=0, momentum=0.9, eta=0.001, weight_decay_filter=False, lars_adaptation_filter=False):
+        defaults = dict(lr=lr, weight_decay=weight_decay, momentum=momentum, eta=eta, weight_decay_filter=weight_decay_filter,
+                        lars_adaptation_filter=lars_adaptation_filter)
+        super().__init__(params, defaults)
+
+    def exclude_bias_and_norm(self, p):
+        return p.ndim == 1
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise ValueError("LARS: parameters and gradients must be contiguous fp32 device tensors")
+                one_d = self.exclude_bias_and_norm(p)
+                wd = 0.0 if (group["weight_decay_filter"] and one_d) else group["weight_decay"]
+                adapt = not (group["lars_adaptation_filter"] and one_d)
+                st = self.state[p]
+                if "mu" not in st:
+                    st["mu"] = torch.zeros_like(p)
+                    st["scratch"] = torch.empty(2, dtype=torch.float32, device=p.device)
+                ops.lars_step(p, p.grad, st["mu"], group["lr"], wd, group["momentum"], group["eta"], adapt, st["scratch"])
+                BF16_WEIGHTS.mark_modified(p)
+
+
+def adjust_learning_rate(args, optimizer, loader, step):
+    """`utils.adjust_learning_rate` (utils/utils.py:47-65, used by main.py:52): linear warm-up over epochs // 100 epochs, then a
+    cosine from base to base / 1000 stretched over 1.25 x the run; base = batch_size / 128 and the result multiplies args.lr
+    (LARS: args.lr_weights / args.lr_biases for groups 0 / 1) -- the reference's double batch-size scaling, kept as is."""
+    import math
+    per_epoch = len(loader)
+    horizon = args.epochs * per_epoch * 1.25
+    warm = int(args.epochs / 100) * per_epoch
+    base = args.batch_size / 128
+    if step < warm:
+        scale = base * step / warm
+    else:
+        frac = (step - warm) / (horizon - warm)
+        w = 0.5 * (1.0 + math.cos(math.pi * frac))
+        scale = base * w + base * 0.001 * (1.0 - w)
+    if args.optimizer == "LARS":
+        optimizer.param_groups[0]["lr"] = scale * args.lr_weights
+        optimizer.param_groups[1]["lr"] = scale * args.lr_biases
+    else:
+        for group in optimizer.param_groups:
+            group["lr"] = scale * args.lr
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """Per-iteration table (utils/utils.py:68-78): linear warm-up, then half a cosine from base_value to final_value."""
+    import numpy as np
+    n_warm = warmup_epochs * niter_per_ep
+    n_rest = epochs * niter_per_ep - n_warm
+    warm = np.linspace(start_warmup_value, base_value, n_warm) if warmup_epochs > 0 else np.array([])
+    k = np.arange(n_rest)
+    rest = final_value + 0.5 * (base_value - final_value) * (1.0 + np.cos(np.pi * k / n_rest))
+    return np.concatenate((warm, rest))
+
+
+def sine_scheduler_increase(final_value, epochs, niter_per_ep, warmup_epochs=0, warmup_value=0):
+    """Mask-ratio table (utils/utils.py:81-91, main.py:442): a constant warm-up at warmup_value, then
+    (final - warmup) * sin(pi/2 * k/n) -- which restarts from 0, not from warmup_value (reference behaviour, kept)."""
+    import numpy as np
+    n_warm = warmup_epochs * niter_per_ep
+    n_rest = epochs * niter_per_ep - n_warm
+    warm = np.full(n_warm, float(warmup_value)) if warmup_epochs > 0 else np.array([])
+    k = np.arange(n_rest)
+    rest = (final_value - warmup_value) * np.sin((np.pi / 2.0) * (k / n_rest))
+    return np.concatenate((warm, rest))

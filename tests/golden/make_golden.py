@@ -466,6 +466,41 @@ def gen_misc():
     save("misc", **out)
 
 
+def gen_optim():
+    """LARS (utils/utils.py:150-189, group layout of main_bt_byol.py:326-345) over three steps, and the three schedule helpers."""
+    out = {}
+    torch.manual_seed(11)
+    w = nn.Parameter(torch.randn(7, 5)); b = nn.Parameter(torch.randn(5)); z = nn.Parameter(torch.zeros(3, 3))
+    opt = ref_utils.LARS([{"params": [w, z], "lr": 0.2}, {"params": [b], "lr": 0.0048}], lr=0, weight_decay=1.5e-2,
+                         weight_decay_filter=True, lars_adaptation_filter=True)
+    out["lars_w0"], out["lars_b0"], out["lars_z0"] = t2n(w).copy(), t2n(b).copy(), t2n(z).copy()
+    for it in range(3):
+        gw, gb, gz = torch.randn(7, 5), torch.randn(5), torch.randn(3, 3) * (1.0 if it else 0.0)   # step 0: zero p AND zero g on z
+        w.grad, b.grad, z.grad = gw.clone(), gb.clone(), gz.clone()
+        out[f"lars_gw{it}"], out[f"lars_gb{it}"], out[f"lars_gz{it}"] = t2n(gw), t2n(gb), t2n(gz)
+        opt.step()
+        out[f"lars_w{it + 1}"], out[f"lars_b{it + 1}"], out[f"lars_z{it + 1}"] = t2n(w).copy(), t2n(b).copy(), t2n(z).copy()
+    out["lars_cfg"] = np.array([0.2, 0.0048, 1.5e-2, 0.9, 0.001])       # lr weights, lr biases, wd, momentum, eta
+    out["cos_sched"] = ref_utils.cosine_scheduler(0.5, 0.01, 5, 7, warmup_epochs=2, start_warmup_value=0.1)
+    out["cos_sched_nowarm"] = ref_utils.cosine_scheduler(1.0, 0.0, 3, 4)
+    out["sine_sched"] = ref_utils.sine_scheduler_increase(0.75, 4, 6, warmup_epochs=1, warmup_value=0.2)
+
+    class _Opt:
+        def __init__(self, n):
+            self.param_groups = [{"lr": -1.0} for _ in range(n)]
+
+    loader = list(range(13))
+    for name, optname, ngroups in [("adamw", "AdamW", 3), ("lars", "LARS", 2)]:
+        args = cfg_ns(epochs=300, batch_size=256, lr=1e-4, lr_weights=0.2, lr_biases=0.0048, optimizer=optname)
+        o = _Opt(ngroups)
+        rows = []
+        for step in [0, 1, 20, 38, 39, 40, 500, 2000, 4000, 4874]:
+            ref_utils.adjust_learning_rate(args, o, loader, step)
+            rows.append([step] + [g["lr"] for g in o.param_groups])
+        out[f"adjust_lr_{name}"] = np.array(rows, dtype=np.float64)
+    save("optim", **out)
+
+
 if __name__ == "__main__":
     gen_bt_loss()
     gen_augment()
@@ -473,3 +508,4 @@ if __name__ == "__main__":
     gen_head()
     gen_step()
     gen_misc()
+    gen_optim()

@@ -373,6 +373,22 @@ def test_main_py_local_crops_vs_oracle(dev, golden):
     assert sorted(errs.values())[len(errs) // 2] < 0.15 and max(errs.values()) < 0.5, worst
 
 
+# ------------------------------------------------------------------------------------------------ LARS
+def test_lars_golden(dev, golden):
+    """utils.LARS with the group layout of main_bt_byol.py:326-345 (weights | biases, both filters on) over three steps against the
+    reference's own optimiser: fp32 elementwise + two norms per tensor, rel 2e-6.  Includes a zero tensor (trust ratio falls to 1)."""
+    g = golden("optim")
+    lr_w, lr_b, wd, mom, eta = [float(x) for x in g["lars_cfg"]]
+    w, b, z = (nn.Parameter(T(g[f"lars_{k}0"], dev)) for k in "wbz")
+    opt = utils.LARS([{"params": [w, z], "lr": lr_w}, {"params": [b], "lr": lr_b}], lr=0, weight_decay=wd, momentum=mom, eta=eta,
+                     weight_decay_filter=True, lars_adaptation_filter=True)
+    for it in range(3):
+        w.grad, b.grad, z.grad = T(g[f"lars_gw{it}"], dev), T(g[f"lars_gb{it}"], dev), T(g[f"lars_gz{it}"], dev)
+        opt.step()
+        for k, prm in (("w", w), ("b", b), ("z", z)):
+            np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"lars_{k}{it + 1}"], rtol=2e-6, atol=1e-7, err_msg=f"{k} step {it}")
+
+
 # ------------------------------------------------------------------------------------------------ the trainer (bench path) vs the oracle
 def test_trainer_step_vs_oracle(dev):
     """Whole hot path: waveform -> log-mel -> views -> ViT-T + projector -> BT loss -> backward -> fused AdamW, against

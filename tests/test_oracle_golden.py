@@ -279,3 +279,40 @@ def test_misc(golden):
         [(str(n), (torch.zeros(2, 2) if str(n) in set(g["pg_regularized"].tolist()) else torch.zeros(2)).requires_grad_(True))
          for n in list(g["pg_regularized"]) + list(g["pg_not_regularized"])])
     assert reg == g["pg_regularized"].tolist() and noreg == g["pg_not_regularized"].tolist()
+
+
+# ------------------------------------------------------------------------------------------------ optimiser family
+def test_lars_oracle_golden(golden):
+    """oracle.step.lars_step vs three steps of the reference's LARS with the filters main_bt_byol.py:344-345 sets."""
+    import torch
+    from oracle import step as ostep
+    g = golden("optim")
+    lr_w, lr_b, wd, mom, eta = [float(x) for x in g["lars_cfg"]]
+    st = {k: (torch.from_numpy(g[f"lars_{k}0"].copy()), torch.zeros_like(torch.from_numpy(g[f"lars_{k}0"].copy()))) for k in "wbz"}
+    for it in range(3):
+        for k, lr in (("w", lr_w), ("z", lr_w), ("b", lr_b)):
+            p, mu = st[k]
+            st[k] = ostep.lars_step(p, torch.from_numpy(g[f"lars_g{k}{it}"]), mu, lr, wd, mom, eta, weight_decay_filter=True, lars_adaptation_filter=True)
+            np.testing.assert_allclose(st[k][0].numpy(), g[f"lars_{k}{it + 1}"], rtol=2e-6, atol=1e-7, err_msg=f"{k} step {it}")
+
+
+def test_schedules_golden(golden):
+    """The product's host-side schedule helpers (ssl_audio_amd.utils) against the reference's tables / learning rates."""
+    import types
+    from ssl_audio_amd import utils
+    g = golden("optim")
+    np.testing.assert_allclose(utils.cosine_scheduler(0.5, 0.01, 5, 7, warmup_epochs=2, start_warmup_value=0.1), g["cos_sched"], rtol=1e-12)
+    np.testing.assert_allclose(utils.cosine_scheduler(1.0, 0.0, 3, 4), g["cos_sched_nowarm"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(utils.sine_scheduler_increase(0.75, 4, 6, warmup_epochs=1, warmup_value=0.2), g["sine_sched"], rtol=1e-12, atol=1e-15)
+
+    class Opt:
+        def __init__(self, n):
+            self.param_groups = [{"lr": -1.0} for _ in range(n)]
+
+    loader = list(range(13))
+    for name, optname, n in [("adamw", "AdamW", 3), ("lars", "LARS", 2)]:
+        args = types.SimpleNamespace(epochs=300, batch_size=256, lr=1e-4, lr_weights=0.2, lr_biases=0.0048, optimizer=optname)
+        o = Opt(n)
+        for row in g[f"adjust_lr_{name}"]:
+            utils.adjust_learning_rate(args, o, loader, int(row[0]))
+            np.testing.assert_allclose([gr["lr"] for gr in o.param_groups], row[1:], rtol=1e-12, atol=1e-18)
