@@ -722,115 +722,6 @@ int launch_p3(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
-// =====================================================================================================
-// 192 x 128 x 64 tile, 384 threads = 6 waves (3 x 2, each 64 x 64), A k-major only (forward and dgrad).
-// Two workgroups still fit a CU (2 x 80 KiB = the whole 160 KiB LDS), so they keep overlapping each other's epilogue
-// like the 128^2 kernel does, while every K-step moves 40 KiB for 3.1 MFLOP instead of 32 KiB for 2.1 MFLOP:
-// 20 % fewer operand bytes per FLOP through the ~28 B/clk/CU L2 -> LDS path that bounds these GEMMs.
-constexpr int A192_BYTES = 192 * 64 * 2;          // 24 KiB
-constexpr int STAGE192 = A192_BYTES + TILE_BYTES;  // 40 KiB
-
-template <bool B_KM>
-__device__ __forceinline__ void stage192(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, char* buf, int lda, int ldb, int m0, int n0,
-                                         int k0, int wave, int lane) {
-  // A: 24 wave-instructions of 1 KiB (8 rows x 128 B) = 4 per wave
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int q = wave * 4 + it;
-    const int row = q * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (row & 7);
-    const uint32_t voff = ((uint32_t)(m0 + row) * (uint32_t)lda + (uint32_t)(k0 + chunk * 8)) * 2u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(buf + q * 1024), 16, voff, 0, 0, 0);
-  }
-  // B: 16 wave-instructions over 6 waves: waves 0-3 issue 3, waves 4-5 issue 2
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int qb = wave + 6 * it;
-    if (qb < 16) {
-      uint32_t voff;
-      if constexpr (B_KM) {
-        const int row = qb * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ (row & 7);
-        voff = ((uint32_t)(n0 + row) * (uint32_t)ldb + (uint32_t)(k0 + chunk * 8)) * 2u;
-      } else {
-        const int krow = qb * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ ks_swz(krow);
-        voff = ((uint32_t)(k0 + krow) * (uint32_t)ldb + (uint32_t)(n0 + chunk * 8)) * 2u;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(buf + A192_BYTES + qb * 1024), 16, voff, 0, 0, 0);
-    }
-  }
-}
-
-template <bool B_KM>
-__global__ __launch_bounds__(384, 3) void gemm192_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A 192x64 | B tile]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  constexpr int GM = 8;
-  const int group_sz = GM * p.tiles_n;
-  const int grp = lid / group_sz, within = lid - grp * group_sz;
-  const int gm = min(GM, p.tiles_m - grp * GM);
-  const int tm = grp * GM + within % gm, tn = within / gm;
-  const int m0 = tm * 192, n0 = tn * 128;
-
-  const int ksteps = (p.K + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  stage192<B_KM>(ra, rb, smem, p.lda, p.ldb, m0, n0, 0, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = 0; kt < ksteps; ++kt) {
-    if (kt + 1 < ksteps) stage192<B_KM>(ra, rb, smem + (cur ^ 1) * STAGE192, p.lda, p.ldb, m0, n0, (kt + 1) * BK, wave, lane);
-    const char* ta = smem + cur * STAGE192;
-    const char* tb = ta + A192_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag<true>(ta, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-  wave_epilogue_64x64(p, acc, m0 + wr * 64, n0 + wc * 64, smem + wave * EPI_BYTES, lane);
-}
-
-template <bool B_KM>
-int launch192(GemmParams p, hipStream_t stream) {
-  p.tiles_m = (p.M + 191) / 192;
-  p.tiles_n = (p.N + 127) / 128;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm192_kernel<B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE192);
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm192_kernel<B_KM>), dim3(p.tiles_m * p.tiles_n), dim3(384), 2 * STAGE192, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(192)");
-  return 0;
-}
 
 // =====================================================================================================
 // Persistent 128 x 128 x 64 kernel (forward / dgrad, no split-K): a workgroup walks tiles lid, lid + grid, ...  The first
@@ -1930,7 +1821,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   static const char* force = getenv("SA_GEMM_TILE");
   const bool big = a->split_k == 1 && a->M >= 1024 && a->N >= 256 && (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 128;
   // Measured on the ViT-B shapes (scripts/bench_gemm.py, random operands): the 128^2 kernel (mode 1, two 4-wave
-  // workgroups per CU) beats the 192x128 (mode 4), 256x128 three-stage (mode 3) and 256^2 (mode 2) variants at K = 768;
+  // workgroups per CU) beats the 256x128 three-stage (mode 3) and 256^2 (mode 2) variants at K = 768;
   // those stay selectable through SA_GEMM_TILE for experiments and are parity-tested.
   // default for large problems: mode 6, the persistent 256 x 256 kernel (measured 12 % faster than mode 1 over the ViT-B
   // forward + dgrad shapes: scripts/bench_gemm.py); small / ragged problems use the plain 128 x 128 kernel.
@@ -1970,10 +1861,6 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     if (a->a_kmajor && !a->b_kmajor) return launch_persist<true, false>(p, stream);
     if (!a->a_kmajor && a->b_kmajor) return launch_persist<false, true>(p, stream);
     return launch_persist<false, false>(p, stream);
-  }
-  if (mode == '4' && a->split_k == 1 && a->a_kmajor) {
-    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 192 tile");
-    return a->b_kmajor ? launch192<true>(p, stream) : launch192<false>(p, stream);
   }
   if (mode == '3' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
