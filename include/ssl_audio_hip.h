@@ -62,6 +62,9 @@ typedef struct SaGemmArgs {
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
+/* Host policy knob (no reference counterpart): CUs the persistent GEMM grids may occupy, 0 = all.  Data-parallel runs reserve
+ * the CUs RCCL's collective kernels hold during an all-reduce, so an overlapped GEMM does not spill into a second wave. */
+int sa_set_cu_budget(int32_t cus);
 
 /* diagnostics only: per-phase cycle stamps of one wave of sa_attention_bwd when SA_ATTN_DBG=8 (4 workgroups x 8 counters, see attention.hip) */
 int sa_attention_debug_counters(uint64_t* out32);

@@ -20,6 +20,15 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 constexpr int NTHREADS = 256;
 
+// CUs the persistent kernels may occupy (0 = all).  Under data parallelism RCCL's collective kernels hold a few CUs for the
+// length of an all-reduce; a persistent grid sized to the whole chip would then run its last workgroups as a second wave and
+// take twice as long, so the host reserves those CUs (sa_set_cu_budget) instead.
+int g_cu_budget = 0;
+inline int budget_slots(int cus, int per_cu = 1) {
+  const int use = (g_cu_budget > 0 && g_cu_budget < cus) ? g_cu_budget : cus;
+  return use * per_cu;
+}
+
 struct GemmParams {
   const char* A; const char* B;
   uint32_t a_bytes, b_bytes;       // buffer extents for the hardware bounds check
@@ -842,7 +851,8 @@ int launch_persist(GemmParams p, hipStream_t stream) {
     configured = true;
   }
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = ntiles < slots ? ntiles : slots;
+  const int use = budget_slots(slots / 2, 2);
+  const int grid = ntiles < use ? ntiles : use;
   hipLaunchKernelGGL((gemm_persist_kernel<A_KM, B_KM>), dim3(grid), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(persistent)");
   return 0;
@@ -1037,7 +1047,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
   if constexpr (A_KM && B_KM) {
     static const char* dbg = getenv("SA_GEMM_DBG");
     if (dbg && atoi(dbg) > 0) {
-      const dim3 g(ntiles < slots ? ntiles : slots), b(512);
+      const dim3 g(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), b(512);
 #define SA_DBG_CASE(D)                                                                                                     \
   case D:                                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, D>),                        \
@@ -1050,7 +1060,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
       return 0;
     }
   }
-  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
   return 0;
 }
@@ -1226,7 +1236,7 @@ int launch256_pp(GemmParams p, hipStream_t stream) {
                               8 * TILE_BYTES);
   }
   const int ntiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm256_pp_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_pp_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 pipelined)");
   return 0;
 }
@@ -1465,7 +1475,7 @@ int launch256_ring(GemmParams p, hipStream_t stream) {
     slots = prop.multiProcessorCount;
   }
   const int nunits = p.tiles_m * p.tiles_n * p.split_k;
-  hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), dim3(nunits < slots ? nunits : slots), dim3(512), 10 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), dim3(nunits < budget_slots(slots) ? nunits : budget_slots(slots)), dim3(512), 10 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 ring)");
   return 0;
 }
@@ -1641,7 +1651,7 @@ int launch256_early(GemmParams p, hipStream_t stream) {
                               8 * TILE_BYTES);
   }
   const int ntiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm256_early_kernel<A_KM, B_KM>), dim3(ntiles < slots ? ntiles : slots), dim3(512), 8 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_early_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 early)");
   return 0;
 }
@@ -1760,6 +1770,12 @@ __global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __r
 
 int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream);
 }  // namespace
+
+extern "C" int sa_set_cu_budget(int32_t cus) {
+  SA_CHECK_ARG(cus >= 0, "sa_set_cu_budget: negative CU count");
+  g_cu_budget = cus;
+  return 0;
+}
 
 extern "C" int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)((M + 63) / 64) * N * (int64_t)sizeof(float); }
 

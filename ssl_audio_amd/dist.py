@@ -42,8 +42,27 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            if RCCL_CUS > 0:                # see reserve_cus_for_collectives
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CUS))
         dist.init_process_group(backend=backend)
     return rank, local, world
+
+
+# RCCL's collective kernels hold one CU per channel for the length of an all-reduce, and a CU cannot host one of them next to
+# a 248-VGPR GEMM workgroup.  A persistent GEMM grid sized to the whole chip that overlaps an all-reduce therefore finishes its
+# last workgroups late (estimated: one ~290 us launch per gradient bucket delayed by up to the ~250 us all-reduce, ~6 % of a
+# step).  SA_RCCL_CUS=n reserves n CUs instead (RCCL bounded to n channels, persistent grids and the split-K heuristic sized
+# to the rest): measured cost 7.5 % of a step through tile-round quantisation (3012 tiles: 12 rounds on 256 CUs, 13 on 240),
+# i.e. no better, so the default is 0 (off).  The real fix is dynamic tile hand-out in the persistent kernels (next round).
+RCCL_CUS = int(os.environ.get("SA_RCCL_CUS", "0"))
+
+
+def reserve_cus_for_collectives():
+    """Called by the trainer once the process group exists (no-op unless SA_RCCL_CUS > 0 and collectives are active)."""
+    from . import ops
+    if RCCL_CUS > 0 and collectives_active() and torch.cuda.is_available() and dist.get_backend() == "nccl":
+        _, cus = ops.device_info()
+        ops.set_cu_budget(max(cus - RCCL_CUS, cus // 2))
 
 
 def collectives_active():

@@ -85,6 +85,16 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes, kname))
 
 
+CU_BUDGET = None      # CUs the big GEMM grids may use (None = the whole device); see set_cu_budget
+
+
+def set_cu_budget(cus):
+    """Reserve CUs for concurrently running collective kernels: persistent GEMM grids and the split-K heuristic use `cus` CUs."""
+    global CU_BUDGET
+    check(lib().sa_set_cu_budget(int(cus or 0)), "sa_set_cu_budget")
+    CU_BUDGET = int(cus) if cus else None
+
+
 def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
     override); used to label bench.py's per-launch timings with the names rocprofv3 reports."""
@@ -96,8 +106,10 @@ def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256):
     return "gemm256_ring_kernel" if (a_kmajor and not b_kmajor) else "gemm256_persist_kernel"
 
 
-def pick_split_k(M, N, K, cu_count=256, tile=128):
+def pick_split_k(M, N, K, cu_count=None, tile=128):
     """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist."""
+    if cu_count is None:
+        cu_count = CU_BUDGET or 256
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     ksteps = (K + 63) // 64
     slots = (2 if tile == 128 else 1) * cu_count       # the 128^2 kernel runs two workgroups per CU, the 256^2 one

@@ -183,6 +183,7 @@ class BarlowTwinsTrainer:
         self.online = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
         self.flat = FlatState(list(self.online.named_parameters()), device)
         self.criterion = BarlowTwinsLoss(cfg, ncrops=2).to(device)
+        sdist.reserve_cus_for_collectives()
         self.sync = GradSync(self.flat)
         engine.BLOCK_DONE_HOOK = self.sync.block_done
         self.predictor = self.target = self.flat_pred = self.flat_target = None
