@@ -3,7 +3,7 @@ import importlib.util
 import os
 import sys
 
-from ssl_audio_amd.utils import (EMA, LARS, MultiCropWrapper, adjust_learning_rate, cosine_scheduler, get_param_groups,  # noqa: F401
+from ssl_audio_amd.utils import (EMA, LARS, MultiCropWrapper, adjust_learning_rate, cosine_scheduler, encode_vit, get_param_groups,  # noqa: F401
                                  get_rank, get_world_size, init_distributed_mode, is_dist_avail_and_initialized, is_main_process,
                                  model_setup_ddp, off_diagonal, save_on_master, sine_scheduler_increase, update_moving_average)
 

@@ -186,6 +186,10 @@ int sa_scatter_add_rows(const float* src, int64_t src_seq_stride, int32_t src_ro
 /* mean pooling of the patch tokens (`x[:, 1:].mean(dim=1)`, models/mae.py:461-462) and its adjoint (row 0 gets zero) */
 int sa_mean_tokens_fwd(const float* y, int32_t S, int32_t N, int32_t d, float* out, void* stream);
 int sa_mean_tokens_bwd(const float* dout, int32_t S, int32_t N, int32_t d, float* dy, void* stream);
+/* eval path (encode_vit, utils/utils.py:278-314): out[s][g][:] (+)= scale * sum_{t<count} y[s][row0 + g*group_stride + t][:]
+ * (mean of stacked CLS embeddings: G=1; mean over time of the patch tokens per frequency row: G = grid rows, stride = grid cols) */
+int sa_token_group_sum(const float* y, int32_t S, int32_t N, int32_t d, int32_t row0, int32_t G, int32_t group_stride, int32_t count,
+                       float scale, int32_t accumulate, float* out, void* stream);
 
 /* MAE decoder input (forward_decoder, models/mae.py:413-420): mask tokens appended, un-shuffled by ids_restore, decoder
  * positional table added.  x [B][1+keep][d], out [B][1+L][d]; bwd WRITES dx (kept rows are a permutation) and ADDS the

@@ -245,3 +245,28 @@ def forward(x, p, num_heads, grid, mean_pool=False, noise=None, mask=None, mask_
         pred = forward_decoder(enc, ids_restore, p, dec_heads)
         return latent, recon_loss(x, pred, m, grid)
     return latent
+
+
+def encode_vit(x, p, num_heads, grid, unit_frames, split_frames=True, use_cls=True):
+    """utils.encode_vit (utils/utils.py:278-314), restated: right-pad to a multiple of unit_frames (a whole extra unit when the
+    length already is one), embed unit by unit, then average the CLS embeddings over units, or lay the patch tokens out as
+    [time, freq x d], drop the frames that came from padding and average over time."""
+    pad = unit_frames - (x.shape[-1] % unit_frames)
+    xp = torch.nn.functional.pad(x, (0, pad))
+    if not split_frames:
+        return forward(xp, p, num_heads, grid)
+    n_units = xp.shape[-1] // unit_frames
+    gf, gt = grid
+    if use_cls:
+        return torch.stack([forward(xp[..., i * unit_frames:(i + 1) * unit_frames], p, num_heads, grid) for i in range(n_units)], 1).mean(1)
+    rows = []
+    for i in range(n_units):
+        enc, _, _ = forward_encoder(xp[..., i * unit_frames:(i + 1) * unit_frames], p, num_heads, grid)
+        tok = enc[:, 1:]                                            # [B, gf * gt, d], frequency-major
+        B, _, d = tok.shape
+        rows.append(tok.reshape(B, gf, gt, d).permute(0, 2, 1, 3).reshape(B, gt, gf * d))
+    seq = torch.cat(rows, 1)
+    drop = int(gt * pad / unit_frames)
+    if drop > 0:
+        seq = seq[:, :-drop]
+    return seq.mean(1)

@@ -211,6 +211,29 @@ __global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, int64_t seq_
   }
 }
 
+// ---- grouped token-row sums for the chunked embedding of the eval path (encode_vit, utils/utils.py:278-314):
+// out[s][g][:] (+)= scale * sum_{t < count} y[s][row0 + g * group_stride + t][:]
+__global__ void token_group_sum_kernel(const float* __restrict__ y, int S, int N, int d, int row0, int G, int group_stride, int count, float scale,
+                                       int accumulate, float* __restrict__ out) {
+  const int nv = d >> 2;
+  const int64_t n = (int64_t)S * G * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nv);
+    const int64_t sg = i / nv;
+    const int g = (int)(sg % G), s = (int)(sg / G);
+    const float4* p = reinterpret_cast<const float4*>(y + ((int64_t)s * N + row0 + (int64_t)g * group_stride) * d) + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < count; ++t) {
+      const float4 v = p[(int64_t)t * nv];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    float4 r = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+    if (accumulate) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+    *o = r;
+  }
+}
+
 inline int grid_for(int64_t n) {
   const int64_t want = (n + 255) / 256;
   return (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
@@ -313,5 +336,16 @@ extern "C" int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride,
   hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, acc2,
                      gscale, B, F, T, ph, pw, dpred);
   SA_LAUNCH_CHECK("sa_mae_recon_loss_bwd");
+  return 0;
+}
+
+extern "C" int sa_token_group_sum(const float* y, int32_t S, int32_t N, int32_t d, int32_t row0, int32_t G, int32_t group_stride, int32_t count,
+                                  float scale, int32_t accumulate, float* out, void* stream) {
+  SA_CHECK_ARG(y && out && S > 0 && N > 0 && d > 0 && d % 4 == 0 && G > 0 && row0 >= 0 && count >= 0 && group_stride >= 0 &&
+                   (count == 0 || row0 + (int64_t)(G - 1) * group_stride + count <= N),
+               "sa_token_group_sum: bad args (groups must lie inside the N token rows, d %% 4 == 0)");
+  hipLaunchKernelGGL(token_group_sum_kernel, dim3(grid_for((int64_t)S * G * (d / 4))), dim3(256), 0, (hipStream_t)stream, y, S, N, d, row0, G,
+                     group_stride, count, scale, accumulate, out);
+  SA_LAUNCH_CHECK("sa_token_group_sum");
   return 0;
 }

@@ -300,6 +300,12 @@ def scatter_add_rows(src, src_seq_stride, src_row0, idx, dst, dst_seq_stride, ds
                                     _stream()), "sa_scatter_add_rows")
 
 
+def token_group_sum(y, row0, G, group_stride, count, scale, out, accumulate=False):
+    S, N, d = y.shape
+    check(lib().sa_token_group_sum(_p(_req(y, F32, "y")), S, N, d, int(row0), int(G), int(group_stride), int(count), float(scale), int(accumulate),
+                                   _p(_req(out, F32, "out")), _stream()), "sa_token_group_sum")
+
+
 def mean_tokens_fwd(y, out):
     S, N, d = y.shape
     check(lib().sa_mean_tokens_fwd(_p(_req(y, F32, "y")), S, N, d, _p(_req(out, F32, "out")), _stream()), "sa_mean_tokens_fwd")

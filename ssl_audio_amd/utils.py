@@ -175,3 +175,40 @@ def sine_scheduler_increase(final_value, epochs, niter_per_ep, warmup_epochs=0, 
     k = np.arange(n_rest)
     rest = (final_value - warmup_value) * np.sin((np.pi / 2.0) * (k / n_rest))
     return np.concatenate((warm, rest))
+
+
+# ------------------------------------------------------------------------------------------------ eval path
+@torch.no_grad()
+def encode_vit(model, x, split_frames=True, use_cls=True):
+    """`utils.encode_vit` (utils/utils.py:278-314): embed a spectrogram of any length with a ViT trained on unit_frames-wide
+    inputs.  The input is right-padded to a multiple of unit_frames (a FULL extra unit when it already is one -- reference
+    behaviour, kept); each unit goes through the encoder; CLS embeddings are averaged over units (use_cls) or the patch tokens
+    are laid out as [time, freq x d], the padded tail dropped and the rest averaged over time.  Encoder and reductions are HIP
+    (sa_token_group_sum); padding / stacking are data movement."""
+    grid_f, grid_t = model.grid_size()
+    d = model.embed_dim
+    unit = model.img_size[1]
+    pad = unit - (x.shape[-1] % unit)
+    xp = torch.zeros(*x.shape[:-1], x.shape[-1] + pad, device=x.device, dtype=x.dtype)
+    xp[..., :x.shape[-1]] = x
+    if not split_frames:
+        return model(xp)
+    n_units = xp.shape[-1] // unit
+    B = x.shape[0]
+    if use_cls:
+        embs = torch.empty(B, n_units, d, device=x.device)
+        for i in range(n_units):
+            embs[:, i] = model(xp[..., i * unit:(i + 1) * unit].contiguous())
+        out = torch.empty(B, 1, d, device=x.device)
+        ops.token_group_sum(embs, 0, 1, 0, n_units, 1.0 / n_units, out)
+        return out.view(B, d)
+    dropped = int(grid_t * pad / unit)                      # embedding frames that came from padding (at most one unit's worth)
+    total = n_units * grid_t - dropped
+    out = torch.zeros(B, grid_f, d, device=x.device)
+    for i in range(n_units):
+        count = min(grid_t, max(0, total - i * grid_t))
+        if count == 0:
+            break
+        tok = model(xp[..., i * unit:(i + 1) * unit].contiguous(), return_all=True)      # [B, 1 + grid_f * grid_t, d]
+        ops.token_group_sum(tok.contiguous(), 1, grid_f, grid_t, count, 1.0 / total, out, accumulate=True)
+    return out.view(B, grid_f * d)

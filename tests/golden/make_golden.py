@@ -501,6 +501,24 @@ def gen_optim():
     save("optim", **out)
 
 
+def gen_eval():
+    """utils.encode_vit (utils/utils.py:278-314) on the micro ViT of vit_micro.npz (weights are NOT stored again)."""
+    g = np.load(os.path.join(HERE, "vit_micro.npz"))
+    m = micro_vit()
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    m.eval()
+    out = {}
+    torch.manual_seed(21)
+    for tag, T_ in [("t222", 222), ("t192", 192), ("t50", 50)]:      # ragged, exact multiple (pads a whole unit), shorter than a unit
+        x = torch.randn(2, 1, 64, T_)
+        out[f"{tag}_x"] = t2n(x)
+        with torch.no_grad():
+            out[f"{tag}_cls"] = t2n(ref_utils.encode_vit(m, x, split_frames=True, use_cls=True))
+            out[f"{tag}_patch"] = t2n(ref_utils.encode_vit(m, x, split_frames=True, use_cls=False))
+            out[f"{tag}_whole"] = t2n(ref_utils.encode_vit(m, x, split_frames=False))
+    save("eval", **out)
+
+
 if __name__ == "__main__":
     gen_bt_loss()
     gen_augment()
@@ -509,3 +527,4 @@ if __name__ == "__main__":
     gen_step()
     gen_misc()
     gen_optim()
+    gen_eval()

@@ -140,6 +140,19 @@ def test_vit_golden(dev, golden, tag, T_):
         assert rel(named[n].grad, g[k]) < 5e-2, n
 
 
+@pytest.mark.parametrize("tag", ["t222", "t192", "t50"])
+def test_encode_vit_golden(dev, golden, tag):
+    """utils.encode_vit (eval path, utils/utils.py:278-314): ragged length, exact multiple of the unit (the reference pads a whole
+    extra unit) and shorter than one unit; CLS, patch-token and unsplit variants.  bf16 encoder: rel 2e-2."""
+    m = micro_vit(dev)
+    load_prefixed(m, golden("vit_micro"), "sd.", dev)
+    g = golden("eval")
+    x = T(g[f"{tag}_x"], dev)
+    assert rel(utils.encode_vit(m, x, split_frames=True, use_cls=True), g[f"{tag}_cls"]) < 2e-2
+    assert rel(utils.encode_vit(m, x, split_frames=True, use_cls=False), g[f"{tag}_patch"]) < 2e-2
+    assert rel(utils.encode_vit(m, x, split_frames=False), g[f"{tag}_whole"]) < 2e-2
+
+
 def test_vit_masking_golden(dev, golden):
     g = golden("vit_micro")
     m = micro_vit(dev)

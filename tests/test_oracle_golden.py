@@ -316,3 +316,14 @@ def test_schedules_golden(golden):
         for row in g[f"adjust_lr_{name}"]:
             utils.adjust_learning_rate(args, o, loader, int(row[0]))
             np.testing.assert_allclose([gr["lr"] for gr in o.param_groups], row[1:], rtol=1e-12, atol=1e-18)
+
+
+@pytest.mark.parametrize("tag", ["t222", "t192", "t50"])
+def test_encode_vit_oracle_golden(golden, tag):
+    """oracle.vit.encode_vit vs the reference's utils.encode_vit (eval path) on the micro ViT."""
+    p = _vit_params(golden("vit_micro"))
+    g = golden("eval")
+    x = T(g[f"{tag}_x"])
+    np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96).numpy(), g[f"{tag}_cls"], atol=5e-5)
+    np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96, use_cls=False).numpy(), g[f"{tag}_patch"], atol=5e-5)
+    np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96, split_frames=False).numpy(), g[f"{tag}_whole"], atol=5e-5)
