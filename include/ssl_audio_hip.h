@@ -169,6 +169,14 @@ int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_s
                      int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream);
 /* NormalizeBatch (augmentations.py:229-232) over n contiguous floats; workspace2 = 2 doubles; shift ~ mean guess */
 int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream);
+/* MixGaussianNoise (augmentations.py:125-141): out = log((1 - lambd) * exp(x) + exp(lambd * normal) + eps); `normal` holds the
+ * caller's N(0,1) draws (torch.normal(0, lambd) == lambd * N(0,1)). */
+int sa_mix_gaussian_noise(const float* x, const float* normal, int64_t n, float lambd, float eps, float* out, void* stream);
+/* RunningNorm (augmentations.py:144-214, axis [1, 2]): state = {running mean, running second moment} per channel, updated while
+ * update != 0 with the reference's increment (divided by the number of samples seen so far, n_seen; first sample initialises),
+ * then out = (x - mean) / max(sqrt(second moment), eps). */
+int sa_running_norm(const float* x, int32_t channels, int64_t per_channel, float* state, int32_t n_seen, int32_t update, float eps,
+                    float* out, void* stream);
 /* [S][1][F][T] fp32 -> bf16 patch rows [S*(F/ph)*(T/pw)][ph*pw] for the patch-embed GEMM (models/mae.py:42) */
 int sa_patchify_bf16(const float* img, void* out, int32_t S, int32_t F, int32_t T, int32_t ph, int32_t pw, void* stream);
 

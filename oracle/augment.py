@@ -167,3 +167,34 @@ class PairTransformOracle:
         for _ in range(self.L):
             crops.append(self._local(x))
         return crops
+
+
+def mix_gaussian_noise(lms, lambd, normal):
+    """MixGaussianNoise.forward (augmentations.py:132-141) with the draws made explicit: lambd = ratio * np.random.rand(),
+    z = exp(N(0, lambd)) = exp(lambd * normal); returns log((1 - lambd) * exp(lms) + z + eps)."""
+    x = np.exp(lms.astype(np.float32))
+    z = np.exp((np.float32(lambd) * normal.astype(np.float32)).astype(np.float32))
+    return np.log((np.float32(1.0 - lambd) * x + z + np.float32(EPS32)).astype(np.float32)).astype(np.float32)
+
+
+class RunningNormOracle:
+    """RunningNorm (augmentations.py:144-214, axis [1, 2]): incremental mean mu += (mean(x) - mu) / n with n = samples seen BEFORE
+    this one (the first sample initialises), the same recurrence on mean((x - mu)^2), std clamped below by eps; frozen after
+    max_update samples."""
+
+    def __init__(self, epoch_samples, max_update_epochs=10):
+        self.max_update = epoch_samples * max_update_epochs
+        self.n = 0
+        self.mu = None
+        self.s2 = None
+
+    def __call__(self, image):
+        x = image.astype(np.float32)
+        if self.n < self.max_update:
+            m = x.mean(axis=(1, 2), keepdims=True, dtype=np.float32)
+            self.mu = m if self.n == 0 else self.mu + (m - self.mu) / np.float32(self.n)
+            v = ((x - self.mu) ** 2).mean(axis=(1, 2), keepdims=True, dtype=np.float32)
+            self.s2 = v if self.n == 0 else self.s2 + (v - self.s2) / np.float32(self.n)
+            self.n += 1
+        std = np.maximum(np.sqrt(self.s2), np.float32(EPS32))
+        return ((x - self.mu) / std).astype(np.float32)

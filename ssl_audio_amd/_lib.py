@@ -46,6 +46,8 @@ _SIGNATURES = {
     "sa_lars_step": [P, P, P, I64, F32, F32, F32, F32, I32, P, P, P],
     "sa_attention_debug_counters": [P],
     "sa_gemm_colsum_workspace_bytes": [I32, I32],
+    "sa_mix_gaussian_noise": [P, P, I64, F32, F32, P, P],
+    "sa_running_norm": [P, I32, I64, P, I32, I32, F32, P, P],
     "sa_token_group_sum": [P, I32, I32, I32, I32, I32, I32, I32, F32, I32, P, P],
     "sa_mean_tokens_fwd": [P, I32, I32, I32, P, P],
     "sa_mean_tokens_bwd": [P, I32, I32, I32, P, P],

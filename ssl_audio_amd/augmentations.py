@@ -10,7 +10,7 @@ Two ways in:
     parameters per view).  Its semantics are the reference's *sequential* ones: view e sees exactly the bank the
     reference's single worker would hold after e earlier views.
 
-MixGaussianNoise / RunningNorm (off by default in the reference) are not provided yet.
+MixGaussianNoise (augmentations.py:125-141) and RunningNorm (:144-214) are provided too (off by default in the reference).
 """
 import random
 
@@ -119,6 +119,65 @@ class MixupBYOLA(nn.Module):
 
     def __repr__(self):
         return self.__class__.__name__ + f'(ratio={self.ratio},n={self.n},log_mixup_exp={self.log_mixup_exp})'
+
+
+class MixGaussianNoise(nn.Module):
+    """log((1 - l) exp(x) + exp(N(0, l)) + eps), l = ratio * np.random.rand() (augmentations.py:125-141).  The normal draws come
+    from torch's generator of the input's device (`normal` overrides them, for parity tests with recorded draws)."""
+
+    def __init__(self, ratio=0.2):
+        super().__init__()
+        self.ratio = ratio
+
+    def forward(self, lms, normal=None):
+        lambd = self.ratio * np.random.rand()
+        x = lms.contiguous().float()
+        if normal is None:
+            normal = torch.randn(x.shape, device=x.device)
+        out = torch.empty_like(x)
+        ops.mix_gaussian_noise(x, normal.contiguous().float(), lambd, EPS32, out)
+        return out
+
+    def __repr__(self):
+        return self.__class__.__name__ + f'(ratio={self.ratio})'
+
+
+class RunningNorm(nn.Module):
+    """Online normalisation with running mean / std over axis [1, 2] (augmentations.py:144-214): statistics are updated for the
+    first epoch_samples * max_update_epochs calls, then frozen.  State lives on the device; one launch per call."""
+
+    def __init__(self, epoch_samples, max_update_epochs=10, axis=[1, 2]):
+        super().__init__()
+        if list(axis) != [1, 2]:
+            raise NotImplementedError("RunningNorm is implemented for the reference's axis=[1, 2]")
+        self.max_update = epoch_samples * max_update_epochs
+        self.axis = list(axis)
+        self.n = 0
+        self.state = None
+
+    def forward(self, image):
+        x = image.contiguous().float()
+        if x.dim() != 3:
+            raise ValueError("RunningNorm expects [C, F, T] inputs")
+        if self.state is None:
+            self.state = torch.zeros(x.shape[0], 2, device=x.device)
+        out = torch.empty_like(x)
+        update = self.n < self.max_update
+        ops.running_norm(x, self.state, self.n, update, EPS32, out)
+        if update:
+            self.n += 1
+        return out
+
+    @property
+    def mean(self):
+        return self.state[:, 0].view(-1, 1, 1)
+
+    @property
+    def std(self):
+        return self.state[:, 1].sqrt().clamp_min(EPS32).view(-1, 1, 1)
+
+    def __repr__(self):
+        return self.__class__.__name__ + f'(max_update={self.max_update},axis={self.axis})'
 
 
 class NormalizeBatch(nn.Module):

@@ -169,6 +169,76 @@ extern "C" int sa_augment_views(const float* lms, int64_t clip_stride, const int
   return 0;
 }
 
+namespace {
+// MixGaussianNoise (augmentations.py:125-141): log((1 - lambda) * exp(x) + exp(lambda * n) + eps), n ~ N(0, 1) supplied by the caller
+__global__ void mix_gaussian_noise_kernel(const float* __restrict__ x, const float* __restrict__ nrm, int64_t n, float lambd, float eps,
+                                          float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = logf((1.f - lambd) * expf(x[i]) + expf(lambd * nrm[i]) + eps);
+}
+
+// RunningNorm (augmentations.py:144-214), one workgroup per channel.  state = {mu, s2} per channel; n_mean / n_var = how many samples the
+// running mean / the running second moment have seen (the reference divides the increment by that count, not count + 1: kept).
+__global__ __launch_bounds__(1024) void running_norm_kernel(const float* __restrict__ x, int64_t per_channel, float* __restrict__ state,
+                                                            int n_seen, int update, float eps, float* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ float bc[2];
+  const float* xc = x + (int64_t)blockIdx.x * per_channel;
+  float* oc = out + (int64_t)blockIdx.x * per_channel;
+  float* st = state + 2 * blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+  };
+  if (update) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < per_channel; i += 1024) s += (double)xc[i];
+    const float m = (float)(block_sum(s) / (double)per_channel);
+    if (threadIdx.x == 0) {
+      const float mu = n_seen == 0 ? m : st[0] + (m - st[0]) / (float)n_seen;
+      st[0] = mu;
+      bc[0] = mu;
+    }
+    __syncthreads();
+    const float mu = bc[0];
+    double q = 0.0;
+    for (int64_t i = threadIdx.x; i < per_channel; i += 1024) {
+      const float dlt = xc[i] - mu;
+      q += (double)(dlt * dlt);
+    }
+    const float v = (float)(block_sum(q) / (double)per_channel);
+    if (threadIdx.x == 0) st[1] = n_seen == 0 ? v : st[1] + (v - st[1]) / (float)n_seen;
+    __syncthreads();
+  }
+  const float mu = st[0];
+  const float sd = fmaxf(sqrtf(st[1]), eps);
+  for (int64_t i = threadIdx.x; i < per_channel; i += 1024) oc[i] = (xc[i] - mu) / sd;
+}
+}  // namespace
+
+extern "C" int sa_mix_gaussian_noise(const float* x, const float* normal, int64_t n, float lambd, float eps, float* out, void* stream) {
+  SA_CHECK_ARG(x && normal && out && n > 0, "sa_mix_gaussian_noise: bad args");
+  const int64_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(mix_gaussian_noise_kernel, dim3((int)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, x, normal, n, lambd, eps, out);
+  SA_LAUNCH_CHECK("sa_mix_gaussian_noise");
+  return 0;
+}
+
+extern "C" int sa_running_norm(const float* x, int32_t channels, int64_t per_channel, float* state, int32_t n_seen, int32_t update, float eps,
+                               float* out, void* stream) {
+  SA_CHECK_ARG(x && state && out && channels > 0 && per_channel > 0 && n_seen >= 0, "sa_running_norm: bad args");
+  hipLaunchKernelGGL(running_norm_kernel, dim3(channels), dim3(1024), 0, (hipStream_t)stream, x, per_channel, state, n_seen, update, eps, out);
+  SA_LAUNCH_CHECK("sa_running_norm");
+  return 0;
+}
+
 extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream) {
   SA_CHECK_ARG(x && y && workspace2 && n > 1, "sa_normalize_batch: bad args");
   if (hipMemsetAsync(workspace2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) {

@@ -300,6 +300,17 @@ def scatter_add_rows(src, src_seq_stride, src_row0, idx, dst, dst_seq_stride, ds
                                     _stream()), "sa_scatter_add_rows")
 
 
+def mix_gaussian_noise(x, normal, lambd, eps, out):
+    check(lib().sa_mix_gaussian_noise(_p(_req(x, F32, "x")), _p(_req(normal, F32, "normal")), x.numel(), float(lambd), float(eps),
+                                      _p(_req(out, F32, "out")), _stream()), "sa_mix_gaussian_noise")
+
+
+def running_norm(x, state, n_seen, update, eps, out):
+    Cn = x.shape[0]
+    check(lib().sa_running_norm(_p(_req(x, F32, "x")), Cn, x.numel() // Cn, _p(_req(state, F32, "state")), int(n_seen), int(bool(update)), float(eps),
+                                _p(_req(out, F32, "out")), _stream()), "sa_running_norm")
+
+
 def token_group_sum(y, row0, G, group_stride, count, scale, out, accumulate=False):
     S, N, d = y.shape
     check(lib().sa_token_group_sum(_p(_req(y, F32, "y")), S, N, d, int(row0), int(G), int(group_stride), int(count), float(scale), int(accumulate),

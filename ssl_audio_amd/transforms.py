@@ -18,7 +18,7 @@ class AudioPairTransform(nn.Module):
             if args.mixup:
                 global_transforms.append(augmentations.MixupBYOLA(ratio=mixup_ratio))
             if args.Gnoise:
-                raise NotImplementedError("MixGaussianNoise (off by default) is not on the MI355X path yet")
+                global_transforms.append(augmentations.MixGaussianNoise(ratio=gauss_noise_ratio))
             if args.RRC:
                 out_size = (args.n_mels, args.crop_frames)
                 global_transforms.append(augmentations.RandomResizeCrop(

@@ -501,6 +501,29 @@ def gen_optim():
     save("optim", **out)
 
 
+def gen_noise_norm():
+    """MixGaussianNoise (draws captured by re-seeding torch) and RunningNorm over five samples with a two-sample update budget."""
+    out = {}
+    torch.manual_seed(3)
+    x = torch.randn(1, 64, 96) * 2.0 - 1.0
+    np.random.seed(5)
+    torch.manual_seed(9)
+    y = ref_aug.MixGaussianNoise(ratio=0.2)(x)
+    np.random.seed(5)
+    lambd = 0.2 * np.random.rand()
+    torch.manual_seed(9)
+    z = torch.normal(0, lambd, x.shape)
+    out["gn_x"], out["gn_y"], out["gn_lambda"], out["gn_normal"] = t2n(x), t2n(y), np.float64(lambd), t2n(z / lambd)
+    rn = ref_aug.RunningNorm(epoch_samples=1, max_update_epochs=3)
+    torch.manual_seed(4)
+    for i in range(5):
+        img = torch.randn(1, 64, 40) * (1.0 + i) + 0.5 * i
+        out[f"rn_x{i}"] = t2n(img)
+        out[f"rn_y{i}"] = t2n(rn(img))
+    out["rn_mean"], out["rn_std"] = t2n(rn.mean), t2n(rn.std)
+    save("noise_norm", **out)
+
+
 def gen_eval():
     """utils.encode_vit (utils/utils.py:278-314) on the micro ViT of vit_micro.npz (weights are NOT stored again)."""
     g = np.load(os.path.join(HERE, "vit_micro.npz"))
@@ -528,3 +551,4 @@ if __name__ == "__main__":
     gen_misc()
     gen_optim()
     gen_eval()
+    gen_noise_norm()

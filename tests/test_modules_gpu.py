@@ -386,6 +386,22 @@ def test_main_py_local_crops_vs_oracle(dev, golden):
     assert sorted(errs.values())[len(errs) // 2] < 0.15 and max(errs.values()) < 0.5, worst
 
 
+# ------------------------------------------------------------------------------------------------ MixGaussianNoise, RunningNorm
+def test_gaussian_noise_and_running_norm_golden(dev, golden):
+    """augmentations.MixGaussianNoise with the reference's recorded draws, and RunningNorm over five samples of which only the
+    first three update the statistics (augmentations.py:125-214)."""
+    g = golden("noise_norm")
+    np.random.seed(5)                                             # -> the same lambda = 0.2 * np.random.rand() as the reference run
+    y = aug.MixGaussianNoise(ratio=0.2)(T(g["gn_x"], dev), normal=T(g["gn_normal"], dev))
+    np.testing.assert_allclose(y.cpu().numpy(), g["gn_y"], rtol=2e-5, atol=5e-6)
+    rn = aug.RunningNorm(epoch_samples=1, max_update_epochs=3)
+    for i in range(5):
+        np.testing.assert_allclose(rn(T(g[f"rn_x{i}"], dev)).cpu().numpy(), g[f"rn_y{i}"], rtol=2e-5, atol=5e-6, err_msg=f"sample {i}")
+    np.testing.assert_allclose(rn.mean.cpu().numpy(), g["rn_mean"], rtol=1e-5)
+    np.testing.assert_allclose(rn.std.cpu().numpy(), g["rn_std"], rtol=1e-5)
+    assert "RunningNorm" in repr(rn) and "MixGaussianNoise" in repr(aug.MixGaussianNoise())
+
+
 # ------------------------------------------------------------------------------------------------ LARS (SURVEY.md §8f row 2)
 def test_lars_golden(dev, golden):
     """utils.LARS with the group layout of main_bt_byol.py:326-345 (weights | biases, both filters on) over three steps against the

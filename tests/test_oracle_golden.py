@@ -327,3 +327,13 @@ def test_encode_vit_oracle_golden(golden, tag):
     np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96).numpy(), g[f"{tag}_cls"], atol=5e-5)
     np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96, use_cls=False).numpy(), g[f"{tag}_patch"], atol=5e-5)
     np.testing.assert_allclose(ovit.encode_vit(x, p, 2, (4, 6), 96, split_frames=False).numpy(), g[f"{tag}_whole"], atol=5e-5)
+
+
+def test_gaussian_noise_and_running_norm_oracle_golden(golden):
+    """MixGaussianNoise (recorded lambda and normal draws) and RunningNorm (3 updating samples, then frozen) vs the reference."""
+    g = golden("noise_norm")
+    np.testing.assert_allclose(oaug.mix_gaussian_noise(g["gn_x"], float(g["gn_lambda"]), g["gn_normal"]), g["gn_y"], rtol=2e-5, atol=2e-6)
+    rn = oaug.RunningNormOracle(epoch_samples=1, max_update_epochs=3)
+    for i in range(5):
+        np.testing.assert_allclose(rn(g[f"rn_x{i}"]), g[f"rn_y{i}"], rtol=2e-5, atol=2e-6, err_msg=f"sample {i}")
+    np.testing.assert_allclose(rn.mu, g["rn_mean"], rtol=1e-5)
