@@ -1,2 +1,2 @@
-from ssl_audio_amd.augmentations import (MixupBYOLA, NormalizeBatch, RandomLinearFader, RandomResizeCrop,  # noqa: F401
-                                         log_mixup_exp)
+from ssl_audio_amd.augmentations import (MixGaussianNoise, MixupBYOLA, NormalizeBatch, RandomLinearFader,  # noqa: F401
+                                         RandomResizeCrop, RunningNorm, log_mixup_exp)

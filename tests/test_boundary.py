@@ -188,3 +188,22 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     g.A, g.B, g.M, g.N, g.K, g.lda, g.ldb, g.split_k = 8, 8, 16, 16, 16, 12, 16, 1        # lda not a multiple of 8 elements
     g.out_f32, g.ldo_f32, g.a_kmajor, g.b_kmajor, g.alpha = 8, 16, 1, 1, 1.0
     assert h.sa_gemm_bf16(C.byref(g), null) != 0 and "sa_gemm_bf16" in h.sa_last_error().decode()
+
+
+def test_driver_import_block_resolves_through_the_shims():
+    """main_bt_byol.py:20-25 imports these names; with amd_shims/ first on sys.path every one must resolve to the MI355X package
+    (`import datasets` is the reference's own data module and stays the reference's)."""
+    import subprocess
+    import sys
+    code = ("from augmentations import RunningNorm, NormalizeBatch\n"
+            "from utils.loss import BarlowTwinsLoss\n"
+            "from utils import utils, transforms, hyperparameters\n"
+            "from model import ModelWrapper, BarlowTwinsHead, BarlowTwinsPredictor\n"
+            "mods = {RunningNorm, NormalizeBatch, BarlowTwinsLoss, ModelWrapper, BarlowTwinsHead, BarlowTwinsPredictor, utils.MultiCropWrapper,\n"
+            "        utils.EMA, utils.LARS, transforms.AudioPairTransform}\n"
+            "assert all(m.__module__.startswith('ssl_audio_amd') for m in mods), [m.__module__ for m in mods]\n"
+            "assert callable(utils.update_moving_average) and callable(utils.adjust_learning_rate) and callable(hyperparameters.get_hyperparameters)\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "amd_shims"), ROOT]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
