@@ -24,8 +24,11 @@ WORKLOADS = {
     "vit_base_bt_10s": ("vit_base", 10.0, 128, "bt"),        # BASELINE configs[2] per-GPU shard (metric's config)
     "vit_tiny_bt_10s": ("vit_tiny", 10.0, 256, "bt"),        # BASELINE configs[1]
     "vit_base_byol_10s": ("vit_base", 10.0, 128, "byol"),    # BASELINE configs[3]
+    "vit_large_mae_10s": ("vit_large", 9.92, 256, "mae"),    # BASELINE configs[4]: ViT-L, 75 % masking + reconstruction, T = 992
 }
-GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol_10s": 357.6}
+GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol_10s": 357.6,
+               # config 5 as main.py runs it: view 1 masked (63 tokens) + decoder, view 2 UNMASKED ViT-L: 3 * (156.6 + 38.6 + 4.0) GF
+               "vit_large_mae_10s": 597.6}
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -113,8 +116,10 @@ def main():
     model_type, seconds, bpg, mode = WORKLOADS[args.workload]
     B = args.batch_per_gpu or bpg
     n_samples = int(seconds * 16000)
-    cfg = hp.make_args(model_type=model_type, batch_size=B * world, crop_frames=n_samples // 160 + 1, dataset="audioset",
-                       stop_gradient=(mode == "byol"), predictor=(mode == "byol"))
+    extra = dict(masked_recon=True, mask=True, mask_ratio=0.75) if mode == "mae" else {}
+    frames = (n_samples // 160 + 1) // 16 * 16 if mode == "mae" else n_samples // 160 + 1      # MAE: whole patches (992)
+    cfg = hp.make_args(model_type=model_type, batch_size=B * world, crop_frames=frames, dataset="audioset",
+                       stop_gradient=(mode == "byol"), predictor=(mode == "byol"), **extra)
     trainer = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=B, clip_samples=n_samples, seed=0)
 
     # synthetic waveforms resident in HBM: 2 alternating batches, distinct per rank (cheap device-side recipe of the

@@ -73,6 +73,9 @@ class ModelWrapper(nn.Module):
                 use_learned_pos_embd=self.cfg.use_learned_pos_embd,
                 use_mean_pool=self.cfg.use_mean_pool,
                 use_decoder=self.cfg.masked_recon,
+                # the MAE decoder's positional table has the constructor grid: with masked reconstruction the model is built for the
+                # training crop (BASELINE config 5); without it the reference's default (64, 96) grid is kept
+                img_size=(self.cfg.n_mels, self.cfg.crop_frames) if (self.cfg.masked_recon and self.cfg.crop_frames % 16 == 0) else None,
             )
         else:
             # resnet* / audiontt encoders run on stock ops in the reference and are not part of this hot path

@@ -170,7 +170,9 @@ class GradSync:
 class BarlowTwinsTrainer:
     """One object = the whole step.  mode='bt': single network, two views, one loss term (main.py:86-119, BASELINE
     configs 2-3).  mode='byol': online (+predictor) / EMA target, two cross terms (main_bt_byol.py --stop_gradient
-    --predictor, BASELINE config 4)."""
+    --predictor, BASELINE config 4).  mode='mae': main.py:69-125 with `--mask --mask_ratio r --masked_recon` (BASELINE config 5):
+    view 1 goes through the masked encoder + MAE decoder (teacher side, adds the reconstruction loss), view 2 through the
+    unmasked encoder, one BT term between them."""
 
     def __init__(self, cfg, device, mode="bt", batch_per_rank=None, clip_samples=160000, seed=0, from_waveform=True,
                  ema_beta=0.99):
@@ -232,6 +234,10 @@ class BarlowTwinsTrainer:
             z = self.online(views, ncrops=2)
             z1, z2 = z.chunk(2)
             loss = self.criterion.forward_loss(z1, z2)
+        elif self.mode == "mae":
+            t, recon = self.online(views[:1], ncrops=1, mask_ratio=self.cfg.mask_ratio, masked_recon=True)
+            st = self.online(views[1:], ncrops=1)
+            loss = self.criterion(st, t, ngcrops_each=1) + recon
         else:
             self.flat_pred.zero_grad()
             o = self.online(views[:2], ncrops=2)

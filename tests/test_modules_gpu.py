@@ -418,6 +418,35 @@ def test_lars_golden(dev, golden):
             np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"lars_{k}{it + 1}"], rtol=2e-6, atol=1e-7, err_msg=f"{k} step {it}")
 
 
+# ------------------------------------------------------------------------------------------------ trainer mode 'mae' (BASELINE config 5 flow)
+def test_trainer_mae_step_vs_oracle(dev):
+    """main.py:69-125 with `--mask --masked_recon` (trainer mode 'mae'): masked view 1 -> encoder + MAE decoder (reconstruction loss),
+    unmasked view 2, one Barlow-Twins term; a fixed mask tensor (models/mae.py:317-323) makes both sides deterministic.
+    ViT-T at T = 96 against the CPU oracle on the same weights and views: loss rel 3e-2 (bf16 through 12 + 4 blocks)."""
+    from oracle import heads as oheads, vit as ovit
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    B = 8
+    g = torch.Generator().manual_seed(3)
+    mask = torch.zeros(B, 24)
+    for b in range(B):
+        mask[b, torch.randperm(24, generator=g)[:18]] = 1                       # 75 % masked
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=B, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       masked_recon=True, mask=True, mask_ratio=mask.to(dev))
+    tr = BarlowTwinsTrainer(cfg, dev, mode="mae", batch_per_rank=B, clip_samples=15200, seed=0, from_waveform=False)
+    sd = {k: v.detach().cpu().clone() for k, v in tr.online.state_dict().items()}
+    views = [torch.randn(B, 1, 64, 96, generator=g), torch.randn(B, 1, 64, 96, generator=g)]
+    loss = float(tr.step_views([v.to(dev) for v in views]))
+    enc = {k[len("backbone.encoder.encoder."):]: v for k, v in sd.items() if k.startswith("backbone.encoder.encoder.")}
+    head = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
+    lat_t, recon = ovit.forward(views[0], enc, 3, (4, 6), mask=mask, masked_recon=True, dec_heads=6)
+    lat_s = ovit.forward(views[1], enc, 3, (4, 6))
+    zt, _ = oheads.head_forward(lat_t, head, 1)
+    zs, _ = oheads.head_forward(lat_s, head, 1)
+    bt, _ = oheads.bt_forward(zs, zt, 2, ngcrops_each=1)
+    ref = float(bt + recon)
+    assert float(recon) > 0 and abs(loss - ref) / abs(ref) < 3e-2, (loss, ref, float(recon))
+
+
 # ------------------------------------------------------------------------------------------------ the trainer (bench path) vs the oracle
 def test_trainer_step_vs_oracle(dev):
     """Whole hot path: waveform -> log-mel -> views -> ViT-T + projector -> BT loss -> backward -> fused AdamW, against
