@@ -191,6 +191,30 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// 16-byte version for buffers whose pointers are 16-byte aligned and whose length is a multiple of 4 (the flat state is)
+__global__ __launch_bounds__(256) void adamw_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                         float4* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float wd,
+                                                         float inv_c1, float inv_sqrt_c2, float grad_scale, bf16x4* __restrict__ p_bf16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 gi = g[i], pi = p[i], mi = m[i], vi = v[i];
+    float gg[4] = {gi.x * grad_scale, gi.y * grad_scale, gi.z * grad_scale, gi.w * grad_scale};
+    float pp[4] = {pi.x, pi.y, pi.z, pi.w}, mm[4] = {mi.x, mi.y, mi.z, mi.w}, vv[4] = {vi.x, vi.y, vi.z, vi.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float q = pp[k] * (1.f - lr * wd);
+      mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+      const float denom = sqrtf(vv[k]) * inv_sqrt_c2 + eps;
+      q -= lr * inv_c1 * mm[k] / denom;
+      pp[k] = q;
+    }
+    p[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (p_bf16) p_bf16[i] = bf16x4{f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])};
+  }
+}
+
 __global__ void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n, float beta) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     tgt[i] = tgt[i] * beta + (1.f - beta) * src[i];
@@ -327,8 +351,14 @@ extern "C" int sa_adamw_step(float* p, const float* g, float* m, float* v, int64
   SA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "sa_adamw_step: bad args");
   if (n == 0) return 0;
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale, (bf16_t*)p_bf16);
+  const bool vec = (n % 4 == 0) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)p_bf16 & 7) == 0);
+  if (vec)
+    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(flat_grid(n / 4, 2)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, n / 4, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale,
+                       (bf16x4*)p_bf16);
+  else
+    hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale, (bf16_t*)p_bf16);
   SA_LAUNCH_CHECK("sa_adamw_step");
   return 0;
 }

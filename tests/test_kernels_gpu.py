@@ -277,8 +277,8 @@ def test_bt_loss_grad(dev, hsic):
     assert rel_err(G, cd.grad) < 1e-6
 
 
-def test_adamw_and_ema(dev):
-    n = 100003
+@pytest.mark.parametrize("n", [100003, 100000])          # scalar path / 16-byte vector path
+def test_adamw_and_ema(dev, n):
     p = rnd((n,), 26); g = rnd((n,), 27, 0.1)
     pr = torch.nn.Parameter(p.clone().double())
     opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.06)
