@@ -45,6 +45,7 @@ struct GemmParams {
   int split_k; int accumulate;
   int tiles_m, tiles_n;
   int gm;   // row-panels per tile group (L2 locality knob)
+  int gm256;         // row-panels per tile group in the 256^2 kernels
   int nt_store;      // bf16 outputs with non-temporal stores
   float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
 };
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const GemmParams p) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  constexpr int GM = 4;
+  const int GM = p.gm256;
   const int group_sz = GM * p.tiles_n;
   const int grp = lid / group_sz, within = lid - grp * group_sz;
   const int gm = min(GM, p.tiles_m - grp * GM);
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int ntiles = p.tiles_m * p.tiles_n;
-  constexpr int GM = 4;
+  const int GM = p.gm256;
   const int group_sz = GM * p.tiles_n;
   auto coords = [&](int t, int& m0, int& n0) {
     const int grp = t / group_sz, within = t - grp * group_sz;
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) 
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int ntiles = p.tiles_m * p.tiles_n;
-  constexpr int GM = 4;
+  const int GM = p.gm256;
   const int group_sz = GM * p.tiles_n;
   auto coords = [&](int t, int& m0, int& n0) {
     const int grp = t / group_sz, within = t - grp * group_sz;
@@ -1267,7 +1268,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int ntiles = p.tiles_m * p.tiles_n;
   const int nunits = ntiles * (SPLIT ? p.split_k : 1);
-  constexpr int GM = 4;
+  const int GM = p.gm256;
   const int group_sz = GM * p.tiles_n;
   const int ksteps_all = (p.K + BK - 1) / BK;
   const int chunk = SPLIT ? (ksteps_all + p.split_k - 1) / p.split_k : ksteps_all;
@@ -1503,7 +1504,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_early_kernel(const GemmParams 
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   const int ntiles = p.tiles_m * p.tiles_n;
-  constexpr int GM = 4;
+  const int GM = p.gm256;
   const int group_sz = GM * p.tiles_n;
   auto coords = [&](int t, int& m0, int& n0) {
     const int grp = t / group_sz, within = t - grp * group_sz;
@@ -1834,6 +1835,9 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
+  static const char* gm256_env = getenv("SA_GEMM_GM256");
+  p.gm256 = gm256_env ? atoi(gm256_env) : 4;
+  if (p.gm256 < 1) p.gm256 = 1;
   static const char* nt_env = getenv("SA_GEMM_NT");
   p.nt_store = nt_env ? atoi(nt_env) : 1;          // SA_GEMM_NT=0 switches the streaming bf16 stores off (measured: +8 % launch time on
                                                     // the qkv / fc1 forward and fc2 dgrad shapes; fp32 outputs and read-once loads: no effect)
