@@ -471,7 +471,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   int cur = 0;
   for (int kt = 0; kt < ksteps; ++kt) {
-    if (kt + 1 < ksteps) stage_all(smem + (cur ^ 1) * BUF, (kt0 + kt + 1) * BK);
+    // the second wave row requests its share of the next K-tile mid-step (see gemm256_persist_kernel): 12-14 % on the wgrad shapes
+    const bool late = p.stagger && wr == 1;
+    if (kt + 1 < ksteps && !late) stage_all(smem + (cur ^ 1) * BUF, (kt0 + kt + 1) * BK);
     const char* ta = smem + cur * BUF + wr * TILE_BYTES;                 // this wave's A half-tile (128 rows)
     const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;    // this wave's B half-tile
     const int bcol = (wc & 1) * 64;
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][2 + j] = (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb1[j][ks], acc[i][2 + j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0));
+    if (kt + 1 < ksteps && late) stage_all(smem + (cur ^ 1) * BUF, (kt0 + kt + 1) * BK);
     // quadrant (1,1)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1844,7 +1847,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
   static const char* stg_env = getenv("SA_GEMM_STAGGER");
-  p.stagger = (stg_env && stg_env[0] == '0') ? 0 : 1;   // default on: measured 2-4 % on the forward shapes (SA_GEMM_STAGGER=0 disables)
+  p.stagger = (stg_env && stg_env[0] == '0') ? 0 : 1;   // default on: measured 2-4 % on the forward shapes, 12-14 % on split-K wgrad (SA_GEMM_STAGGER=0 disables)
   static const char* gm256_env = getenv("SA_GEMM_GM256");
   p.gm256 = gm256_env ? atoi(gm256_env) : 4;
   if (p.gm256 < 1) p.gm256 = 1;
