@@ -47,6 +47,7 @@ struct GemmParams {
   int gm;   // row-panels per tile group (L2 locality knob)
   int gm256;         // row-panels per tile group in the 256^2 kernels
   int stagger;       // persistent 256^2 kernel: wave row 1 requests its LDS-DMA share mid-step
+  int ring_phase;    // ring kernel: requests phased by wave row
   int nt_store;      // bf16 outputs with non-temporal stores
   float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
 };
@@ -1362,6 +1363,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
       const char* ta = smem + ca * HALF + wr * TILE_BYTES;
       const char* tb = smem + cb * HALF + (wc >> 1) * TILE_BYTES;
       bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+      // request phases: wave row 0 sends its eight requests during Q0/Q1 (two per 8 MFMAs), row 1 during Q2/Q3 -- each SIMD's two
+      // waves are then never both stalled on the memory pipe's issue queue (3-8 % over the uniform one-per-8-MFMAs trickle)
+      const bool phased = p.ring_phase != 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1377,7 +1381,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][j] = SA_MM(fa[i][ks], fb0[j][ks], acc[i][j]);
-            if (i == 3 && j == 1 && pending) issue_b(pb, ks);          // requests trickle out every 8 MFMAs: a burst of 8 stalls
+            if (i == 3 && j == 1 && pending) {                          // requests trickle out every 8 MFMAs: a burst of 8 stalls
+              if (!phased) issue_b(pb, ks);
+              else if (wr == 0) { issue_b(pb, 2 * ks); issue_b(pb, 2 * ks + 1); }
+            }
           }                                                              // every wave on the memory pipe's issue queue
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -1390,7 +1397,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][2 + j] = SA_MM(fa[i][ks], fb1[j][ks], acc[i][2 + j]);
-            if (i == 3 && j == 1 && pending) issue_b(pb, 2 + ks);
+            if (i == 3 && j == 1 && pending) {
+              if (!phased) issue_b(pb, 2 + ks);
+              else if (wr == 0) { issue_a(pa, 2 * ks); issue_a(pa, 2 * ks + 1); }
+            }
           }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1403,7 +1413,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[4 + i][2 + j] = SA_MM(fa[i][ks], fb1[j][ks], acc[4 + i][2 + j]);
-            if (i == 3 && j == 1 && pending) issue_a(pa, ks);
+            if (i == 3 && j == 1 && pending) {
+              if (!phased) issue_a(pa, ks);
+              else if (wr == 1) { issue_b(pb, 2 * ks); issue_b(pb, 2 * ks + 1); }
+            }
           }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1412,7 +1425,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[4 + i][j] = SA_MM(fa[i][ks], fb0[j][ks], acc[4 + i][j]);
-            if (i == 3 && j == 1 && pending) issue_a(pa, 2 + ks);
+            if (i == 3 && j == 1 && pending) {
+              if (!phased) issue_a(pa, 2 + ks);
+              else if (wr == 1) { issue_a(pa, 2 * ks); issue_a(pa, 2 * ks + 1); }
+            }
           }
       // ---- K-step barrier: the next K-tile has landed, this one is no longer read
       if (fresh) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1846,6 +1862,8 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
+  static const char* rp_env = getenv("SA_GEMM_RING_PHASE");
+  p.ring_phase = (rp_env && rp_env[0] == '0') ? 0 : 1;   // default on: 3-8 % on the dgrad shapes (SA_GEMM_RING_PHASE=0: uniform trickle)
   static const char* stg_env = getenv("SA_GEMM_STAGGER");
   p.stagger = (stg_env && stg_env[0] == '0') ? 0 : 1;   // default on: measured 2-4 % on the forward shapes, 12-14 % on split-K wgrad (SA_GEMM_STAGGER=0 disables)
   static const char* gm256_env = getenv("SA_GEMM_GM256");
