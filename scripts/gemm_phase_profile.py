@@ -15,12 +15,12 @@ for name, (N, K) in shapes.items():
     bias = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     for _ in range(3):
-        ops.gemm(a, w, b_kmajor=True, bias=bias, out_bf16=out)
+        ops.gemm(a, w, b_kmajor=True, bias=(None if os.environ.get("SA_PROFILE_NO_BIAS") else bias), out_bf16=out)
     buf = (ctypes.c_uint64 * 16)()
     assert lib().sa_gemm_debug_counters(buf) == 0
     for wg in range(2):
-        steps, mfma, vm, bar, epi, total, top = [buf[wg * 8 + i] for i in range(7)]
+        steps, mfma, vm, bar, epi, total, top, ebar = [buf[wg * 8 + i] for i in range(8)]
         if steps == 0:
             continue
         print(f"{name:5s} wg{wg}: steps={steps:4d} total={total:9d} clk | per K-step: frag+mfma {mfma/steps:7.0f}  vmcnt-wait {vm/steps:7.0f}  "
-              f"barrier {bar/steps:6.0f} | per tile: epilogue {epi/(steps/(K//64)):8.0f}  tile-top wait {top/(steps/(K//64)):7.0f}")
+              f"barrier {bar/steps:6.0f} | per tile: epilogue {epi/(steps/(K//64)):8.0f} (of which pre-epilogue barrier {ebar/(steps/(K//64)):7.0f})  tile-top wait {top/(steps/(K//64)):7.0f}")

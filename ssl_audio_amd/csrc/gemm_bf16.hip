@@ -48,6 +48,7 @@ struct GemmParams {
   int gm256;         // row-panels per tile group in the 256^2 kernels
   int stagger;       // persistent 256^2 kernel: wave row 1 requests its LDS-DMA share mid-step
   int ring_phase;    // ring kernel: requests phased by wave row
+  int epi_kind;      // 1..4: one of the compact epilogues applies (wave_epilogue_compact); 0: general epilogue
   int nt_store;      // bf16 outputs with non-temporal stores
   float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
 };
@@ -215,13 +216,100 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32
                           : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
     if (m < p.M) {
       const int64_t orow = (remap && p.row_group > 0) ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-      if (p.nt_store) {   // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels: streaming stores that do not displace the operands in L2
+      if (p.nt_store == 2) {
+        asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));     // timing experiment: no global store at all
+      } else if (p.nt_store) {   // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels: streaming stores that do not displace the operands in L2
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dst + orow * ld + n_base + ch * 8));
       } else {
         *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
       }
     }
+  }
+}
+
+// Compact epilogues for the four combinations the ViT blocks use (whole 64-column block inside N, aligned outputs).  The general
+// epilogue below is thousands of instructions of mostly-untaken paths with spilled scalars; a once-per-tile walk through it was
+// measured at 15 k cycles per 256 x 256 tile even for a bias-only epilogue, against 9 k for the compact path.
+//   kind 1: alpha * acc + bias -> bf16                                   (qkv forward, every dgrad without an activation)
+//   kind 2: alpha * acc + bias -> aux_out (bf16), GELU -> bf16           (fc1 forward)
+//   kind 3: alpha * acc + bias + residual -> fp32                        (proj / fc2 forward)
+//   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad)
+template <bool SWZ, int kind>
+__device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
+  if (n_base >= p.N) return;                    // N is a multiple of 64 here: a 64-column block is wholly inside or wholly outside
+  const int g = lane >> 4, c = lane & 15;
+  const float alpha = p.alpha;
+  if constexpr (kind != 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j][0] = acc[i][j][0] * alpha + b.x; acc[i][j][1] = acc[i][j][1] * alpha + b.y;
+        acc[i][j][2] = acc[i][j][2] * alpha + b.z; acc[i][j][3] = acc[i][j][3] * alpha + b.w;
+      }
+    }
+  }
+  if constexpr (kind == 1) {
+    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
+  } else if constexpr (kind == 2) {
+    staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_f(acc[i][j][r]);
+      __builtin_amdgcn_sched_barrier(0);               // 16 activations at a time: 64 interleaved erf chains spill
+    }
+    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
+  } else if constexpr (kind == 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_base + i * 16 + c;
+      if (m >= p.M) continue;
+      const float* rrow = p.residual + (int64_t)m * p.ldr + n_base + 4 * g;
+      float* orow = p.out_f32 + (int64_t)m * p.ldo_f32 + n_base + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 rv = *reinterpret_cast<const float4*>(rrow + j * 16);
+        *reinterpret_cast<float4*>(orow + j * 16) =
+            make_float4(acc[i][j][0] + rv.x, acc[i][j][1] + rv.y, acc[i][j][2] + rv.z, acc[i][j][3] + rv.w);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_base + i * 16 + c;
+      if (m >= p.M) continue;
+      const bf16_t* arow = p.aux_in + (int64_t)m * p.ldaux + n_base + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(arow + j * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * dgelu_f(bf2f(h[r]));
+      }
+    }
+    if (p.colsum_ws && m_base < p.M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float cs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+          cs[r] = t;
+        }
+        if (c == 0) *reinterpret_cast<float4*>(p.colsum_ws + (int64_t)(m_base >> 6) * p.N + n_base + j * 16 + 4 * g) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      }
+    }
+    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
   }
 }
 
@@ -312,6 +400,10 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(w + j * 16) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
     }
+  }
+  if (p.nt_store == 3) {                                 // timing experiment: no staging, no stores
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[3][3]), "v"(acc[1][2]), "v"(acc[2][1]));
+    return;
   }
   if (p.out_bf16) staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
 }
@@ -887,7 +979,7 @@ __device__ __forceinline__ f32x4 mfma_dbg(const bf16x8& x, const bf16x8& y, cons
   }
 }
 
-template <bool A_KM, bool B_KM, int DBG = 0>
+template <bool A_KM, bool B_KM, int DBG = 0, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
   constexpr int BUF = 4 * TILE_BYTES;
@@ -924,7 +1016,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   coords(t, m0, n0);
   stage_all(smem, m0, n0, 0);
   int cur = 0;
-  unsigned long long pc_mfma = 0, pc_vm = 0, pc_bar = 0, pc_epi = 0, pc_top = 0, pc_steps = 0;
+  unsigned long long pc_mfma = 0, pc_vm = 0, pc_bar = 0, pc_epi = 0, pc_top = 0, pc_steps = 0, pc_ebar = 0;
   const unsigned long long pc_begin = SA_STAMP();
   while (true) {
     const unsigned long long tt0 = SA_STAMP();
@@ -1023,9 +1115,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     const unsigned long long e0 = SA_STAMP();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // raw: the next tile's LDS-DMA stays in flight
+    pc_ebar += SA_STAMP() - e0;
     char* wl = smem + cur * BUF + wave * 8192;
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    if constexpr (EPI != 0) {
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    } else {
+      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+    }
     pc_epi += SA_STAMP() - e0;
     if (!has_next) break;
     t = tnext; m0 = m0n; n0 = n0n;
@@ -1035,7 +1133,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     const int which = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
     if (which >= 0 && threadIdx.x == 64 * 5) {          // wave 5 of two workgroups
       unsigned long long* o = sa_gemm_prof[which];
-      o[0] = pc_steps; o[1] = pc_mfma; o[2] = pc_vm; o[3] = pc_bar; o[4] = pc_epi; o[5] = SA_STAMP() - pc_begin; o[6] = pc_top;
+      o[0] = pc_steps; o[1] = pc_mfma; o[2] = pc_vm; o[3] = pc_bar; o[4] = pc_epi; o[5] = SA_STAMP() - pc_begin; o[6] = pc_top; o[7] = pc_ebar;
     }
   }
 }
@@ -1073,7 +1171,24 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
       return 0;
     }
   }
-  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
+  const dim3 grid(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots));
+  if constexpr (A_KM && B_KM) {            // the forward layout gets kernels specialised on the compact epilogues 1..3
+#define SA_EPI_CASE(E)                                                                                                     \
+  case E: {                                                                                                                \
+    static bool cfg = false;                                                                                               \
+    if (!cfg) {                                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, 0, E>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                               \
+      cfg = true;                                                                                                          \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, 0, E>), grid, dim3(512), 8 * TILE_BYTES, stream, p);             \
+    SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
+    return 0;                                                                                                              \
+  }
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) default: break; }   // kind 2 (erf-GELU over 64 values) spills at 256 VGPRs: general path
+#undef SA_EPI_CASE
+  }
+  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
   return 0;
 }
@@ -1266,7 +1381,7 @@ int launch256_pp(GemmParams p, hipStream_t stream) {
 //   into the two slots step g has just finished reading.
 // Requests past the end of the stream go out of range (zero fill, no traffic) so the outstanding count stays exact; the
 // K-step right after an epilogue waits vmcnt(0) because stores / atomics sit between the loads in the counter.
-template <bool A_KM, bool B_KM, bool SPLIT>
+template <bool A_KM, bool B_KM, bool SPLIT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HALF = 2 * TILE_BYTES;               // 32 KiB: [rows 0..127 | rows 128..255] of one operand
@@ -1461,8 +1576,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
         }
     } else {
       char* wl = smem + (wave < 4 ? ea * HALF + wave * 8192 : eb * HALF + (wave - 4) * 8192);
-      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
-      wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+      if constexpr (EPI != 0) {
+        wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+        wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+      } else {
+        wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
+        wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+      }
     }
     u += nwg;
     if (u >= nunits) break;
@@ -1503,7 +1623,27 @@ int launch256_ring(GemmParams p, hipStream_t stream) {
     slots = prop.multiProcessorCount;
   }
   const int nunits = p.tiles_m * p.tiles_n * p.split_k;
-  hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), dim3(nunits < budget_slots(slots) ? nunits : budget_slots(slots)), dim3(512), 10 * TILE_BYTES, stream, p);
+  const dim3 grid(nunits < budget_slots(slots) ? nunits : budget_slots(slots));
+  if constexpr (A_KM && !B_KM && !SPLIT) {  // the dgrad layout gets kernels specialised on the compact epilogues 1 and 4
+#define SA_EPI_CASE(E)                                                                                                     \
+  case E: {                                                                                                                \
+    static bool cfg = false;                                                                                               \
+    if (!cfg) {                                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_ring_kernel<true, false, false, E>),                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 10 * TILE_BYTES) != hipSuccess) {                \
+        sa_set_error("sa_gemm_bf16: 160 KiB of LDS per workgroup refused");                                                \
+        return 2;                                                                                                          \
+      }                                                                                                                    \
+      cfg = true;                                                                                                          \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((gemm256_ring_kernel<true, false, false, E>), grid, dim3(512), 10 * TILE_BYTES, stream, p);          \
+    SA_LAUNCH_CHECK("sa_gemm_bf16(256 ring, compact epilogue)");                                                           \
+    return 0;                                                                                                              \
+  }
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(4) default: break; }
+#undef SA_EPI_CASE
+  }
+  hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), grid, dim3(512), 10 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 ring)");
   return 0;
 }
@@ -1862,6 +2002,19 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
+  static const char* es_env = getenv("SA_GEMM_EPI_COMPACT");
+  p.epi_kind = 0;
+  {
+    const bool al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; }(a->out_bf16) && [](const void* q) { return ((uintptr_t)q & 15) == 0; }(a->aux_out) &&
+                      [](const void* q) { return ((uintptr_t)q & 7) == 0; }(a->aux_in);
+    const bool base_ok = !(es_env && es_env[0] == '0') && a->split_k == 1 && a->row_group == 0 && a->res_mod == 0 && !a->accumulate && a->N % 64 == 0 && al16;
+    const bool bf16_only = a->out_bf16 && !a->out_f32 && a->ldo_bf16 % 8 == 0 && !a->residual;
+    if (base_ok && bf16_only && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out) p.epi_kind = 1;
+    else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;
+    else if (base_ok && a->out_f32 && !a->out_bf16 && a->residual && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out &&
+             a->ldr % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->residual | (uintptr_t)a->out_f32) & 15) == 0) p.epi_kind = 3;
+    else if (base_ok && bf16_only && a->act == 2 && a->aux_in && !a->bias && a->ldaux % 4 == 0) p.epi_kind = 4;
+  }
   static const char* rp_env = getenv("SA_GEMM_RING_PHASE");
   p.ring_phase = (rp_env && rp_env[0] == '0') ? 0 : 1;   // default on: 3-8 % on the dgrad shapes (SA_GEMM_RING_PHASE=0: uniform trickle)
   static const char* stg_env = getenv("SA_GEMM_STAGGER");

@@ -30,6 +30,34 @@ def main():
             e16 = float((out16.cpu().double() - ref).norm() / ref.norm())
             assert e32 < 1e-5 and e16 < 4e-3, (a_km, b_km, e32, e16)
             worst = max(worst, e32)
+    # same shapes with N a multiple of 64 but not of 256 (the last column tile is partly outside N): compact epilogues must skip it
+    N64 = 2112
+    B64 = bf(torch.randn(N64, K, generator=g) * 0.1); bias64 = torch.randn(N64, generator=g); res64 = torch.randn(M, N64, generator=g)
+    acc64 = A.double() @ B64.double().T
+    for b_km in (True, False):
+        Bd = (B64 if b_km else B64.T.contiguous()).to(dev)
+        guard = torch.full((M + 2, N64), 7.0, device=dev, dtype=torch.bfloat16)                   # rows after the output must stay untouched
+        ops.gemm(A.to(dev), Bd, b_kmajor=b_km, bias=bias64.to(dev), out_bf16=guard[:M])
+        r1 = acc64 + bias64.double()
+        assert float((guard[:M].cpu().double() - r1).norm() / r1.norm()) < 4e-3 and float((guard[M:].float() - 7.0).abs().max()) == 0.0
+        o32 = torch.full((M + 2, N64), 7.0, device=dev)
+        ops.gemm(A.to(dev), Bd, b_kmajor=b_km, bias=bias64.to(dev), residual=res64.to(dev), out_f32=o32[:M])
+        r3 = acc64 + bias64.double() + res64.double()
+        assert float((o32[:M].cpu().double() - r3).norm() / r3.norm()) < 1e-5 and float((o32[M:] - 7.0).abs().max()) == 0.0
+    # the compact epilogues of the large kernels: bias -> bf16 only (qkv forward / plain dgrad), bias + residual -> fp32 only (proj / fc2)
+    for a_km, b_km in ((True, True), (True, False)):
+        Bd = (B if b_km else B.T.contiguous()).to(dev)
+        o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(A.to(dev), Bd, b_kmajor=b_km, bias=bias.to(dev), out_bf16=o16)
+        r1 = acc + bias.double()
+        assert float((o16.cpu().double() - r1).norm() / r1.norm()) < 4e-3
+        o32 = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(A.to(dev), Bd, b_kmajor=b_km, bias=bias.to(dev), residual=res.to(dev), out_f32=o32)
+        r3 = acc + bias.double() + res.double()
+        assert float((o32.cpu().double() - r3).norm() / r3.norm()) < 1e-5
+        o16b = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(A.to(dev), Bd, b_kmajor=b_km, out_bf16=o16b, alpha=0.5)
+        assert float((o16b.cpu().double() - 0.5 * acc).norm() / (0.5 * acc).norm()) < 4e-3
     # GELU epilogue with the pre-activation side output (forward fc1) and its derivative (dgrad through fc2)
     pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16); h = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     ops.gemm(A.to(dev), B.to(dev), bias=bias.to(dev), act=1, aux_out=pre, out_bf16=h)
