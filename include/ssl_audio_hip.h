@@ -42,7 +42,10 @@ typedef struct SaGemmArgs {
   float alpha;
   const float* bias;            /* [N] fp32 or NULL */
   int32_t act;                  /* 0 none | 1 GELU(erf); pre-activation copied to aux_out if non-NULL
-                                   | 2 multiply by GELU'(aux_in[m][n]) (backward through fc1's activation) */
+                                   | 2 multiply by GELU'(aux_in[m][n]) (backward through fc1's activation, aux = pre-activation)
+                                   | 3 GELU(erf); aux_out receives GELU'(pre-activation) -- the exponential is shared, so the
+                                       derivative is free in the forward and the backward needs no transcendental
+                                   | 4 multiply by aux_in[m][n] (backward partner of 3) */
   const void* aux_in;           /* bf16 [M][ldaux] */
   void* aux_out;                /* bf16 [M][ldaux] */
   int64_t ldaux;

@@ -132,11 +132,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4&
     for (int r = 0; r < 4 && n + r < p.N; ++r) {
       float x = a[r] * p.alpha;
       if (p.bias) x += p.bias[n + r];
-      if (p.act == 1) {
-        if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
+      if (p.act == 1 || p.act == 3) {
+        if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(p.act == 3 ? dgelu_f(x) : x);
         x = gelu_f(x);
-      } else if (p.act == 2) {
-        x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
+      } else if (p.act == 2 || p.act == 4) {
+        const float h = bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]);
+        x *= p.act == 4 ? h : dgelu_f(h);
       }
       if (p.residual) x += p.residual[rrow * p.ldr + n + r];
       if (p.out_f32) {
@@ -152,17 +153,18 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4&
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
-  if (p.act == 1) {
+  if (p.act == 1 || p.act == 3) {
     if (p.aux_out) {
       bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      if (p.act == 3) h = bf16x4{f2bf(dgelu_f(v[0])), f2bf(dgelu_f(v[1])), f2bf(dgelu_f(v[2])), f2bf(dgelu_f(v[3]))};
       *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-  } else if (p.act == 2) {
+  } else if (p.act == 2 || p.act == 4) {
     const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+    for (int r = 0; r < 4; ++r) v[r] *= p.act == 4 ? bf2f(h[r]) : dgelu_f(bf2f(h[r]));
   }
   if (p.residual) {
     const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
@@ -192,8 +194,8 @@ constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
 // SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by (row & 7),
 // exactly 8 KiB per wave -- four waves fit one 32 KiB pipeline stage (the persistent kernel stages its epilogue in the
 // stage it has just finished reading while the other stage already receives the next tile).
-template <bool SWZ>
-__device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32x4 (&v)[4][4], char* wlds, bf16_t* dst, int64_t ld,
+template <bool SWZ, int XF = 0>   // XF = 1: store GELU'(v) and REPLACE v by GELU(v) (forward fc1 with act = 3; one exp + one rcp for both)
+__device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v)[4][4], char* wlds, bf16_t* dst, int64_t ld,
                                                   int m_base, int n_base, bool remap, int lane) {
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -201,6 +203,16 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bf16x4 h = {f2bf(v[i][j][0]), f2bf(v[i][j][1]), f2bf(v[i][j][2]), f2bf(v[i][j][3])};
+      if constexpr (XF == 1) {
+        float dy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float y;
+          gelu_pair(v[i][j][r], y, dy[r]);
+          v[i][j][r] = y;
+        }
+        h = bf16x4{f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
+      }
       const int row = i * 16 + c;
       if constexpr (SWZ)
         *reinterpret_cast<bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = h;
@@ -234,13 +246,14 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, const f32
 //   kind 1: alpha * acc + bias -> bf16                                   (qkv forward, every dgrad without an activation)
 //   kind 2: alpha * acc + bias -> aux_out (bf16), GELU -> bf16           (fc1 forward)
 //   kind 3: alpha * acc + bias + residual -> fp32                        (proj / fc2 forward)
-//   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad)
+//   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad, act 2: aux holds the pre-activation)
+//   kind 5: alpha * acc * aux_in -> bf16 (+ column sums)                 (fc2 dgrad, act 4: aux already holds GELU')
 template <bool SWZ, int kind>
 __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
   if (n_base >= p.N) return;                    // N is a multiple of 64 here: a 64-column block is wholly inside or wholly outside
   const int g = lane >> 4, c = lane & 15;
   const float alpha = p.alpha;
-  if constexpr (kind != 4) {
+  if constexpr (kind != 4 && kind != 5) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -290,7 +303,7 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
       for (int j = 0; j < 4; ++j) {
         const bf16x4 h = *reinterpret_cast<const bf16x4*>(arow + j * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * dgelu_f(bf2f(h[r]));
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * (kind == 5 ? bf2f(h[r]) : dgelu_f(bf2f(h[r])));
       }
     }
     if (p.colsum_ws && m_base < p.M) {
@@ -342,7 +355,9 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
       acc[i][j][2] = acc[i][j][2] * p.alpha + b.z; acc[i][j][3] = acc[i][j][3] * p.alpha + b.w;
     }
   }
-  if (p.act == 1) {
+  if (p.act == 3) {                                  // (act = 3 always comes with aux_out)
+    staged_store_bf16<SWZ, 1>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
+  } else if (p.act == 1) {
     if (p.aux_out) staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -361,10 +376,10 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n_base + j * 16 + 4 * g;
-      if (p.act == 2) {
+      if (p.act == 2 || p.act == 4) {
         const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] *= dgelu_f(bf2f(h[r]));
+        for (int r = 0; r < 4; ++r) acc[i][j][r] *= p.act == 4 ? bf2f(h[r]) : dgelu_f(bf2f(h[r]));
       }
       if (p.residual) {
         const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
@@ -651,11 +666,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
           float x = acc[i][j][r] * p.alpha;
           if (p.bias) x += p.bias[n + r];
-          if (p.act == 1) {
-            if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(x);
+          if (p.act == 1 || p.act == 3) {
+            if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(p.act == 3 ? dgelu_f(x) : x);
             x = gelu_f(x);
-          } else if (p.act == 2) {
-            x *= dgelu_f(bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]));
+          } else if (p.act == 2 || p.act == 4) {
+            const float h = bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]);
+            x *= p.act == 4 ? h : dgelu_f(h);
           }
           if (p.residual) x += p.residual[rrow * p.ldr + n + r];
           if (p.out_f32) {
@@ -671,17 +687,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      if (p.act == 1) {
+      if (p.act == 1 || p.act == 3) {
         if (p.aux_out) {
           bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          if (p.act == 3) h = bf16x4{f2bf(dgelu_f(v[0])), f2bf(dgelu_f(v[1])), f2bf(dgelu_f(v[2])), f2bf(dgelu_f(v[3]))};
           *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.act == 2) {
+      } else if (p.act == 2 || p.act == 4) {
         const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(bf2f(h[r]));
+        for (int r = 0; r < 4; ++r) v[r] *= p.act == 4 ? bf2f(h[r]) : dgelu_f(bf2f(h[r]));
       }
       if (p.residual) {
         const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
@@ -1640,7 +1657,7 @@ int launch256_ring(GemmParams p, hipStream_t stream) {
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 ring, compact epilogue)");                                                           \
     return 0;                                                                                                              \
   }
-    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(4) default: break; }
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(4) SA_EPI_CASE(5) default: break; }
 #undef SA_EPI_CASE
   }
   hipLaunchKernelGGL((gemm256_ring_kernel<A_KM, B_KM, SPLIT>), grid, dim3(512), 10 * TILE_BYTES, stream, p);
@@ -1976,7 +1993,9 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   if (a->split_k > 1)
     SA_CHECK_ARG(a->out_f32 && !a->out_bf16 && !a->bias && !a->act && !a->residual && !a->row_group,
                  "sa_gemm_bf16: split_k > 1 supports only alpha and fp32 atomic accumulation");
-  if (a->act == 2) SA_CHECK_ARG(a->aux_in != nullptr, "sa_gemm_bf16: act=2 needs aux_in");
+  SA_CHECK_ARG(a->act >= 0 && a->act <= 4, "sa_gemm_bf16: act must be 0..4");
+  if (a->act == 2 || a->act == 4) SA_CHECK_ARG(a->aux_in != nullptr, "sa_gemm_bf16: act=2/4 needs aux_in");
+  if (a->act == 3) SA_CHECK_ARG(a->aux_out != nullptr, "sa_gemm_bf16: act=3 needs aux_out");
   if (a->out_f32) SA_CHECK_ARG(a->ldo_f32 % 4 == 0 && ((uintptr_t)a->out_f32 & 15) == 0, "sa_gemm_bf16: fp32 output must be 16-byte aligned rows");
   if (a->out_bf16) SA_CHECK_ARG(a->ldo_bf16 % 4 == 0 && ((uintptr_t)a->out_bf16 & 7) == 0, "sa_gemm_bf16: bf16 output rows must be 8-byte aligned");
   if (a->residual) SA_CHECK_ARG(a->ldr % 4 == 0 && ((uintptr_t)a->residual & 15) == 0, "sa_gemm_bf16: residual must be 16-byte aligned rows");
@@ -2010,10 +2029,10 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     const bool base_ok = !(es_env && es_env[0] == '0') && a->split_k == 1 && a->row_group == 0 && a->res_mod == 0 && !a->accumulate && a->N % 64 == 0 && al16;
     const bool bf16_only = a->out_bf16 && !a->out_f32 && a->ldo_bf16 % 8 == 0 && !a->residual;
     if (base_ok && bf16_only && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out) p.epi_kind = 1;
-    else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;
+    else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;   // (not dispatched: spills)
     else if (base_ok && a->out_f32 && !a->out_bf16 && a->residual && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out &&
              a->ldr % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->residual | (uintptr_t)a->out_f32) & 15) == 0) p.epi_kind = 3;
-    else if (base_ok && bf16_only && a->act == 2 && a->aux_in && !a->bias && a->ldaux % 4 == 0) p.epi_kind = 4;
+    else if (base_ok && bf16_only && (a->act == 2 || a->act == 4) && a->aux_in && !a->bias && a->ldaux % 4 == 0) p.epi_kind = a->act == 2 ? 4 : 5;
   }
   static const char* rp_env = getenv("SA_GEMM_RING_PHASE");
   p.ring_phase = (rp_env && rp_env[0] == '0') ? 0 : 1;   // default on: 3-8 % on the dgrad shapes (SA_GEMM_RING_PHASE=0: uniform trickle)

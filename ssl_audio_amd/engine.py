@@ -20,6 +20,9 @@ import torch
 from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
+# fc1 forward stores GELU'(pre-activation) (act 3) and the fc2 dgrad multiplies by it (act 4); SA_ACT_PAIR=0 falls back to the
+# pre-activation form (act 1 / 2) for A/B measurements
+_ACT_PAIR = __import__("os").environ.get("SA_ACT_PAIR", "1") != "0"
 
 
 class _Bf16Cache:
@@ -125,7 +128,8 @@ def block_forward(x, p, H, N, eps, save):
     hidden = p.w1.shape[0]
     pre = torch.empty(M, hidden, dtype=BF16, device=dev) if save is not None else None
     a = torch.empty(M, hidden, dtype=BF16, device=dev)
-    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=1, aux_out=pre, out_bf16=a)
+    # with a backward to come, `pre` receives GELU'(pre-activation) (act 3): all the backward needs, and free next to GELU itself
+    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=(3 if _ACT_PAIR else 1) if pre is not None else 1, aux_out=pre, out_bf16=a)
     x3 = torch.empty(M, d, device=dev)
     ops.gemm(a, W(p.w2), bias=p.b2.detach(), residual=x2, out_f32=x3)
     if save is not None:
@@ -149,7 +153,7 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
         ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
     fuse_b1 = pre.shape[1] % 64 == 0                  # fc1's bias gradient = column sums of dpre: taken in the epilogue that produces it
-    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
+    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=4 if _ACT_PAIR else 2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
     # fc1
     _wgrad(dpre, h2, g.w1)
     if not fuse_b1:
@@ -209,7 +213,8 @@ def block_forward_cls(x, p, H, N, eps, save):
     hidden = p.w1.shape[0]
     pre = torch.empty(S, hidden, dtype=BF16, device=dev) if save is not None else None
     a = torch.empty(S, hidden, dtype=BF16, device=dev)
-    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=1, aux_out=pre, out_bf16=a)
+    # with a backward to come, `pre` receives GELU'(pre-activation) (act 3): all the backward needs, and free next to GELU itself
+    ops.gemm(h2, W(p.w1), bias=p.b1.detach(), act=(3 if _ACT_PAIR else 1) if pre is not None else 1, aux_out=pre, out_bf16=a)
     x3 = torch.empty(S, d, device=dev)
     ops.gemm(a, W(p.w2), bias=p.b2.detach(), residual=x2, out_f32=x3)
     if save is not None:
@@ -227,7 +232,7 @@ def block_backward_cls(dx3, dx3_16, p, g, H, N, saved, prev_b2=None):
     _wgrad(dx3_16, a, g.w2)
     ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
-    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=2, aux_in=pre, out_bf16=dpre)
+    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=4 if _ACT_PAIR else 2, aux_in=pre, out_bf16=dpre)
     _wgrad(dpre, h2, g.w1)
     ops.colsum_bf16(dpre, g.b1, accumulate=True)
     dh2 = torch.empty(S, d, dtype=BF16, device=dev)

@@ -71,6 +71,19 @@ def main():
     torch.nn.functional.gelu(xx).sum().backward()
     refd = acc * xx.grad
     assert float((d.cpu().double() - refd).norm() / refd.norm()) < 4e-3
+    # act 3 (GELU, aux = GELU') and act 4 (multiply by aux) on the large kernels, with the fused column sums on a 64-aligned width
+    dgl = torch.empty(M, N64, device=dev, dtype=torch.bfloat16); h3 = torch.empty(M, N64, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), B64.to(dev), bias=bias64.to(dev), act=3, aux_out=dgl, out_bf16=h3)
+    x64 = (acc64 + bias64.double()).requires_grad_(True)
+    gx64 = torch.nn.functional.gelu(x64)
+    gx64.sum().backward()
+    assert float((h3.cpu().double() - gx64.detach()).norm() / gx64.detach().norm()) < 4e-3
+    assert float((dgl.cpu().double() - x64.grad).norm() / x64.grad.norm()) < 4e-3
+    d4 = torch.empty(M, N64, device=dev, dtype=torch.bfloat16); cs = torch.zeros(N64, device=dev)
+    ops.gemm(A.to(dev), B64.T.contiguous().to(dev), b_kmajor=False, act=4, aux_in=dgl, out_bf16=d4, colsum_out=cs)
+    ref4 = acc64 * dgl.cpu().double()
+    assert float((d4.cpu().double() - ref4).norm() / ref4.norm()) < 4e-3
+    assert float((cs.cpu().double() - ref4.sum(0)).norm() / ref4.sum(0).norm()) < 1e-4
     # split-K wgrad on the 256 tile (TN), ragged reduction
     T, Nw, Kw = 9000 + 17, 704, 1032
     dY = bf(torch.randn(T, Nw, generator=g)); X = bf(torch.randn(T, Kw, generator=g))

@@ -75,6 +75,14 @@ def test_gemm_epilogues(dev):
     hh = hb.double().requires_grad_(True)
     torch.nn.functional.gelu(hh).sum().backward()
     assert rel_err(out32, acc * hh.grad) < 2e-5
+    # act 3 / 4: the forward stores GELU'(h) instead of h, the backward multiplies by it (same results as act 1 / 2)
+    dg = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=3, aux_out=dg, out_f32=out32)
+    hh2 = h.clone().requires_grad_(True)
+    torch.nn.functional.gelu(hh2).sum().backward()
+    assert rel_err(out32, ref) < 2e-5 and rel_err(dg, hh2.grad) < 4e-3
+    ops.gemm(A.to(dev), W.to(dev), act=4, aux_in=dg, out_f32=out32)
+    assert rel_err(out32, acc * dg.cpu().double()) < 2e-5
     # bias + residual, alpha, accumulate
     ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), residual=res.to(dev), alpha=0.5, out_f32=out32)
     assert rel_err(out32, 0.5 * acc + bias.double() + res.double()) < 1e-5
