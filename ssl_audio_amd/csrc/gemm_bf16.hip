@@ -248,12 +248,13 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
 //   kind 3: alpha * acc + bias + residual -> fp32                        (proj / fc2 forward)
 //   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad, act 2: aux holds the pre-activation)
 //   kind 5: alpha * acc * aux_in -> bf16 (+ column sums)                 (fc2 dgrad, act 4: aux already holds GELU')
+//   kind 6: alpha * acc + bias -> aux_out = GELU'(.), bf16 = GELU(.)     (fc1 forward, act 3)
 template <bool SWZ, int kind>
 __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
   if (n_base >= p.N) return;                    // N is a multiple of 64 here: a 64-column block is wholly inside or wholly outside
   const int g = lane >> 4, c = lane & 15;
   const float alpha = p.alpha;
-  if constexpr (kind != 4 && kind != 5) {
+  if constexpr (kind != 4 && kind != 5) {   // (kinds 1, 2, 3, 6 start from alpha * acc + bias)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,6 +267,9 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
     }
   }
   if constexpr (kind == 1) {
+    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
+  } else if constexpr (kind == 6) {          // fc1 forward, act 3: aux <- GELU'(v), acc <- GELU(v) in one pass, then the activation
+    staged_store_bf16<SWZ, 1>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
     staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
   } else if constexpr (kind == 2) {
     staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
@@ -1202,7 +1206,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
     return 0;                                                                                                              \
   }
-    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) default: break; }   // kind 2 (erf-GELU over 64 values) spills at 256 VGPRs: general path
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(6) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
 #undef SA_EPI_CASE
   }
   hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), 8 * TILE_BYTES, stream, p);
@@ -2030,6 +2034,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     const bool bf16_only = a->out_bf16 && !a->out_f32 && a->ldo_bf16 % 8 == 0 && !a->residual;
     if (base_ok && bf16_only && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out) p.epi_kind = 1;
     else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;   // (not dispatched: spills)
+    else if (base_ok && bf16_only && a->act == 3 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 6;
     else if (base_ok && a->out_f32 && !a->out_bf16 && a->residual && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out &&
              a->ldr % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->residual | (uintptr_t)a->out_f32) & 15) == 0) p.epi_kind = 3;
     else if (base_ok && bf16_only && (a->act == 2 || a->act == 4) && a->aux_in && !a->bias && a->ldaux % 4 == 0) p.epi_kind = a->act == 2 ? 4 : 5;
