@@ -240,6 +240,20 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
   }
 }
 
+// Mirror of staged_store_bf16 for an epilogue INPUT: a row-per-lane read of aux_in touches 16 rows x 32 B per instruction (a quarter
+// of every 128-byte line it pulls in); going through the wave's LDS scratch reads whole 128-byte row segments instead.  Swizzled layout only.
+__device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds, const bf16_t* src, int64_t ld, int m_base, int n_base, int lane) {
+  const int ch = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int m = m_base + r;
+    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    if (m < p.M) val = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + n_base + ch * 8);
+    *reinterpret_cast<uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4)) = val;
+  }
+}
+
 // Compact epilogues for the four combinations the ViT blocks use (whole 64-column block inside N, aligned outputs).  The general
 // epilogue below is thousands of instructions of mostly-untaken paths with spilled scalars; a once-per-tile walk through it was
 // measured at 15 k cycles per 256 x 256 tile even for a bias-only epilogue, against 9 k for the compact path.
@@ -298,14 +312,14 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
       }
     }
   } else {
+    static_assert(SWZ, "the compact epilogues stage through the swizzled 8 KiB scratch");
+    staged_load_bf16(p, wlds, p.aux_in, p.ldaux, m_base, n_base, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m_base + i * 16 + c;
-      if (m >= p.M) continue;
-      const bf16_t* arow = p.aux_in + (int64_t)m * p.ldaux + n_base + 4 * g;
+      const int row = i * 16 + c;                       // rows past M were staged as zeros: their products are zero, nothing is stored
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(arow + j * 16);
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * (kind == 5 ? bf2f(h[r]) : dgelu_f(bf2f(h[r])));
       }
@@ -2037,7 +2051,8 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     else if (base_ok && bf16_only && a->act == 3 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 6;
     else if (base_ok && a->out_f32 && !a->out_bf16 && a->residual && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out &&
              a->ldr % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->residual | (uintptr_t)a->out_f32) & 15) == 0) p.epi_kind = 3;
-    else if (base_ok && bf16_only && (a->act == 2 || a->act == 4) && a->aux_in && !a->bias && a->ldaux % 4 == 0) p.epi_kind = a->act == 2 ? 4 : 5;
+    else if (base_ok && bf16_only && (a->act == 2 || a->act == 4) && a->aux_in && !a->bias && a->ldaux % 8 == 0 && ((uintptr_t)a->aux_in & 15) == 0)
+      p.epi_kind = a->act == 2 ? 4 : 5;
   }
   static const char* rp_env = getenv("SA_GEMM_RING_PHASE");
   p.ring_phase = (rp_env && rp_env[0] == '0') ? 0 : 1;   // default on: 3-8 % on the dgrad shapes (SA_GEMM_RING_PHASE=0: uniform trickle)
