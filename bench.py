@@ -33,21 +33,25 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(workload, budget_clips=8, steps=16):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample."""
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample of the SAME step the
+    GPU leg runs: oracle.step.bt_step (bt), bt_byol_step with EMA target + predictor (byol), mae_step with 75 % masking (mae)."""
     from oracle import step as ostep, vit as ovit
     from ssl_audio_amd.selfcheck import synthetic_waveforms
     from oracle import frontend as ofe, augment as oaug
     import numpy as np
-    model_type, seconds, _, _ = WORKLOADS[workload]
+    model_type, seconds, _, mode = WORKLOADS[workload]
     size = model_type.split("_")[-1]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(avail, 32)                        # measured: 256 threads on this small batch is 50x SLOWER than 32 (oversubscription)
     torch.set_num_threads(cores)
     n_samples = int(seconds * 16000)
     T = n_samples // 160 + 1
-    heads = {"tiny": 3, "small": 6, "base": 12}[size]
+    if mode == "mae":
+        T = T // 16 * 16                          # whole patches (992), like the GPU leg
+    heads = ovit.VIT_SIZES[size]["num_heads"]
     d = ovit.VIT_SIZES[size]["embed_dim"]
-    enc = ovit.init_params(size, seed=0)
+    grid = (4, T // 16) if mode == "mae" else (4, 6)
+    enc = ovit.init_params(size, seed=0, use_decoder=(mode == "mae"), img_size=(64, T) if mode == "mae" else (64, 96))
     sd = {"backbone.encoder.encoder." + k: v for k, v in enc.items()}
     g = torch.Generator().manual_seed(1)
     sd["head.projector.0.weight"] = torch.randn(8192, d, generator=g) * 0.02
@@ -55,6 +59,12 @@ def cpu_baseline(workload, budget_clips=8, steps=16):
     sd["head.projector.1.running_mean"], sd["head.projector.1.running_var"] = torch.zeros(8192), torch.ones(8192)
     sd["head.projector.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
     sd["head.projector.3.weight"] = torch.randn(256, 8192, generator=g) * 0.02
+    target = {k: v.clone() for k, v in sd.items()} if mode == "byol" else None
+    pred = None
+    if mode == "byol":
+        pred = {"predictor.0.weight": torch.randn(256, 256, generator=g) * 0.05, "predictor.1.weight": torch.ones(256),
+                "predictor.1.bias": torch.zeros(256), "predictor.1.running_mean": torch.zeros(256), "predictor.1.running_var": torch.ones(256),
+                "predictor.1.num_batches_tracked": torch.zeros((), dtype=torch.long), "predictor.3.weight": torch.randn(256, 256, generator=g) * 0.05}
     opt = ostep.AdamW(1e-4, 0.06)
     all_waves = synthetic_waveforms(budget_clips, n_samples).numpy()
     tfm = oaug.PairTransformOracle(crop_frames=T, seed=0)
@@ -67,7 +77,11 @@ def cpu_baseline(workload, budget_clips=8, steps=16):
             c = tfm(lms[b][None])
             v[0].append(c[0]); v[1].append(c[1])
         views = [torch.from_numpy(np.stack(x)).float() for x in v]
-        return ostep.bt_step(sd, views, heads, (4, 6), opt)[0]
+        if mode == "byol":
+            return ostep.bt_byol_step(sd, target, pred, views, heads, grid, opt, True, True)[0]
+        if mode == "mae":
+            return ostep.mae_step(sd, views, heads, grid, opt, noise=torch.rand(n_clips, grid[0] * grid[1], generator=g), mask_ratio=0.75)[0]
+        return ostep.bt_step(sd, views, heads, grid, opt)[0]
 
     t0 = time.time()
     one_step(2)                                   # warm-up on 2 clips (also sizes the sample: about 15 s of CPU work)
@@ -80,7 +94,7 @@ def cpu_baseline(workload, budget_clips=8, steps=16):
         one_step()
     dt = time.time() - t0
     return {"value": budget_clips * steps / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{budget_clips} clips x {steps} step(s) after a 2-clip warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
+            "sample": f"{budget_clips} clips x {steps} step(s) of the '{mode}' step after a 2-clip warm-up, {model_type}, {seconds:g} s clips, fp32 torch CPU, "
                       f"{torch.get_num_threads()} threads of {avail} visible cores (oracle/: frontend + augment + fwd/bwd + AdamW)"}
 
 
@@ -157,6 +171,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    trainer.assert_finite()                                        # the step's device-side finite-loss counter, read once here
     note(f"timed region done: {args.steps} steps in {dt:.3f}s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -211,8 +226,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only (rank 0 is the only rank)
             note("timing the CPU baseline (oracle on host cores) ...")
-            line["cpu_baseline"] = cpu_baseline(args.workload)
-            note("CPU baseline done")
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.workload)
+                note("CPU baseline done")
+            except Exception as e:  # noqa: BLE001  -- the GPU result is never lost to a failure of the CPU leg
+                line["cpu_baseline"] = None
+                note(f"CPU baseline FAILED: {e!r}")
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -114,10 +114,12 @@ int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32
  *   bwd_stats: s1[c] = sum_b g, s2[c] = sum_b g*xhat, g = dy * [ReLU mask]  (dbeta = s1, dgamma = s2)
  *   bwd_apply: dx = gamma * rstd * (g - s1*inv_n - xhat * s2*inv_n), s1/s2 summed over ranks, inv_n = 1/global rows */
 int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, float* mean, float* m2, void* stream);
-/* finalize: combine W ranks' (mean, m2) rows ([W][2][C], equal rows_per_rank) -> global mean, rstd = rsqrt(var+eps);
- * optionally updates running_mean / running_var (momentum, unbiased variance) as nn.BatchNorm1d does in train mode */
-int sa_bn_finalize(const float* stats, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum, float* mean,
-                   float* rstd, float* running_mean, float* running_var, void* stream);
+/* finalize: combine W ranks' (mean, m2) rows ([W][2][C], equal rows_per_rank; rank r's block starts at stats + r * rank_stride,
+ * rank_stride = 0 means 2*C -- a larger stride reads one tensor's statistics out of a packed all-gather of several) -> global
+ * mean, rstd = rsqrt(var+eps); optionally updates running_mean / running_var (momentum, unbiased variance) as nn.BatchNorm1d
+ * does in train mode */
+int sa_bn_finalize(const float* stats, int64_t rank_stride, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum,
+                   float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
 int sa_bn_apply(const float* x, int64_t ld, int32_t B, int32_t C, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, int32_t relu, float* y_f32, void* y_bf16, int64_t ldy, void* stream);
 int sa_bn_bwd_stats(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int32_t B, int32_t C,
@@ -150,6 +152,9 @@ int sa_lars_step(float* p, const float* g, float* mu, int64_t n, float lr, float
                  int32_t lars_adaptation, float* scratch2, void* p_bf16, void* stream);
 /* y += a * x on flat fp32 buffers (gradient accumulation of small vectors) */
 int sa_axpy_f32(float* y, const float* x, int64_t n, float a, void* stream);
+/* flag[0] += number of non-finite values in x[0..n): the device-side half of the reference's per-step `math.isfinite(loss.item())`
+ * guard (main_bt_byol.py:116-118).  The host reads the flag every k steps instead of synchronising every step. */
+int sa_count_nonfinite(const float* x, int64_t n, int32_t* flag, void* stream);
 
 /* ------------------------------------------------------------------ log-mel frontend
  * Replaces torchaudio MelSpectrogram + log at datasets.py:39-48,115 and crop/pad/normalise at datasets.py:342-354.
@@ -218,6 +223,9 @@ int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pr
                           float* acc2, float* loss, void* stream);
 int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
                           int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream);
+/* loss[0] = acc2[0] / acc2[1] again, after acc2 was summed over data-parallel ranks (global masked mean: what one process computes
+ * on the global batch, models/mae.py:451-452). */
+int sa_mae_recon_loss_finalize(const float* acc2, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,8 @@ utils/utils.py:23-27 (off_diagonal).  Batch-norm running statistics are returned
 import torch
 import torch.nn.functional as F
 
+from . import rounding as R   # identity hooks unless rounding.mirror_hip_bf16() is active
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -37,10 +39,10 @@ def mlp_bn_relu(x, w0, g, b, w1, ncrops):
     (BarlowTwinsHead.forward model.py:25-31 / BarlowTwinsPredictor.forward model.py:47-53)."""
     outs, stats = [], []
     for xc in x.chunk(ncrops):
-        h = F.linear(xc, w0)
+        h = R.qb(F.linear(R.qf(xc), R.qw(w0)))
         hn, mu, var = batchnorm_train(h, g, b)
         stats.append((mu, var, h.shape[0]))
-        outs.append(F.linear(F.relu(hn), w1))
+        outs.append(R.qb(F.linear(R.qf(F.relu(hn)), R.qw(w1))))
     return torch.cat(outs), stats
 
 

@@ -173,3 +173,28 @@ def bt_step(sd, views, num_heads, grid, opt, alpha=1.0, lmbda=0.005):
     decay = {k for k in params if not (k.endswith(".bias") or sd[k].dim() == 1)}
     opt.step(params, grads, decay)
     return float(loss.detach()), grads
+
+
+def mae_step(sd, views, num_heads, grid, opt, mask=None, noise=None, mask_ratio=0.75, dec_heads=6, alpha=1.0, lmbda=0.005):
+    """main.py:69-125 with `--mask --masked_recon` and L = 0 (BASELINE config 5's step): view 1 through the masked encoder + MAE
+    decoder (teacher side; adds the reconstruction loss, models/mae.py:464-468), view 2 through the unmasked encoder, one
+    Barlow-Twins term forward_loss(teacher, student).  The masking randomness is explicit: `mask` [B, L] or `noise` [B, L]."""
+    tr = trainable_names(sd)
+    leaf = _leafify(sd, set(tr))
+    pre = "backbone.encoder.encoder." if any(k.startswith("backbone.encoder.encoder.") for k in sd) else "backbone.encoder."
+    enc = {k[len(pre):]: v for k, v in leaf.items() if k.startswith(pre)}
+    head = {k[len("head."):]: v for k, v in leaf.items() if k.startswith("head.")}
+    lat_t, recon = vit.forward(views[0], enc, num_heads, grid, mask=mask, noise=noise, mask_ratio=mask_ratio, masked_recon=True,
+                               dec_heads=dec_heads)
+    lat_s = vit.forward(views[1], enc, num_heads, grid)
+    zt, st_t = heads.head_forward(lat_t, head, 1)
+    zs, st_s = heads.head_forward(lat_s, head, 1)
+    apply_bn_buffers(sd, "head.projector.1.", st_t + st_s)
+    bt, _ = heads.bt_forward(zs, zt, 2, ngcrops_each=1, alpha=alpha, lmbda=lmbda)
+    loss = bt + recon
+    gs = torch.autograd.grad(loss, [leaf[k] for k in tr], allow_unused=True)
+    params = {k: sd[k] for k, g in zip(tr, gs) if g is not None}
+    grads = {k: g for k, g in zip(tr, gs) if g is not None}
+    decay = {k for k in params if not (k.endswith(".bias") or sd[k].dim() == 1)}
+    opt.step(params, grads, decay)
+    return float(loss.detach()), grads

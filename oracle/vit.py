@@ -10,6 +10,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import rounding as R   # identity hooks unless rounding.mirror_hip_bf16() is active (see oracle/rounding.py)
+
 LN_EPS = 1e-6  # models/mae.py:495 partial(nn.LayerNorm, eps=1e-6)
 
 VIT_SIZES = {  # models/mae.py:492-517 (+ "large": extension for BASELINE config 5)
@@ -145,26 +147,26 @@ def attention(x, p, pre, num_heads):
     B, N, C = x.shape
     qb, vb = p[pre + "q_bias"], p[pre + "v_bias"]
     bias = torch.cat((qb, torch.zeros_like(vb), vb))
-    qkv = F.linear(x, p[pre + "qkv.weight"], bias).reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
+    qkv = R.q(F.linear(x, R.qw(p[pre + "qkv.weight"]), bias)).reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.unbind(0)
-    attn = ((q @ k.transpose(-2, -1)) * (C // num_heads) ** -0.5).softmax(dim=-1)
-    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
-    return F.linear(x, p[pre + "proj.weight"], p[pre + "proj.bias"])
+    attn = R.qf(R.qb((q @ k.transpose(-2, -1)) * (C // num_heads) ** -0.5).softmax(dim=-1))
+    x = R.q((attn @ v).transpose(1, 2).reshape(B, N, C))
+    return R.qb(F.linear(x, R.qw(p[pre + "proj.weight"]), p[pre + "proj.bias"]))
 
 
 def block(x, p, pre, num_heads):
     """BlockKBiasZero.forward (models/mae.py:157-163); Mlp = fc1 -> exact-erf GELU -> fc2."""
     C = x.shape[-1]
-    x = x + attention(F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS), p, pre + "attn.", num_heads)
-    h = F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS)
-    h = F.linear(F.gelu(F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])), p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
-    return x + h
+    x = x + attention(R.q(F.layer_norm(x, (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS)), p, pre + "attn.", num_heads)
+    h = R.q(F.layer_norm(x, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS))
+    h = R.gelu(F.linear(h, R.qw(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"]))
+    return x + R.qb(F.linear(h, R.qw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]))
 
 
 def patch_embed(x, p):
     """PatchEmbed.forward (models/mae.py:40-43)."""
     w = p["patch_embed.proj.weight"]
-    return F.conv2d(x, w, p["patch_embed.proj.bias"], stride=w.shape[-2:]).flatten(2).transpose(1, 2)
+    return F.conv2d(R.qf(x), R.qw(w), p["patch_embed.proj.bias"], stride=w.shape[-2:]).flatten(2).transpose(1, 2)
 
 
 def masking_from_noise(x, noise=None, mask=None, mask_ratio=0.0):
@@ -218,7 +220,7 @@ def patchify(imgs, grid, patch=(16, 16)):
 
 def forward_decoder(x, ids_restore, p, dec_heads):
     """forward_decoder (models/mae.py:411-435)."""
-    x = F.linear(x, p["decoder_embed.weight"], p["decoder_embed.bias"])
+    x = R.qb(F.linear(R.qf(x), R.qw(p["decoder_embed.weight"]), p["decoder_embed.bias"]))
     n_mask = ids_restore.shape[1] + 1 - x.shape[1]
     x_ = torch.cat([x[:, 1:], p["mask_token"].expand(x.shape[0], n_mask, -1)], dim=1)
     x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).expand(-1, -1, x.shape[2]))
@@ -227,7 +229,7 @@ def forward_decoder(x, ids_restore, p, dec_heads):
         x = block(x, p, f"decoder_blocks.{i}.", dec_heads)
     C = x.shape[-1]
     x = F.layer_norm(x, (C,), p["decoder_norm.weight"], p["decoder_norm.bias"], LN_EPS)
-    return F.linear(x, p["decoder_pred.weight"], p["decoder_pred.bias"])[:, 1:]
+    return R.qb(F.linear(R.qf(x), R.qw(p["decoder_pred.weight"]), p["decoder_pred.bias"]))[:, 1:]
 
 
 def recon_loss(imgs, pred, mask, grid):

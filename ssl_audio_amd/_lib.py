@@ -55,18 +55,20 @@ _SIGNATURES = {
     "sa_mae_unshuffle_bwd": [P, I32, P, I32, I32, I32, P, P, P],
     "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, P, P, P],
     "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P],
+    "sa_mae_recon_loss_finalize": [P, P, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],
     "sa_bn_apply": [P, I64, I32, I32, P, P, P, P, I32, P, P, I64, P],
     "sa_bn_bwd_stats": [P, I32, I64, P, I64, I32, I32, P, P, P, P, I32, P, P, P],
     "sa_bn_bwd_apply": [P, I32, I64, P, I64, I32, I32, P, P, P, P, I32, P, P, F32, P, P, P, I64, P],
-    "sa_bn_finalize": [P, I32, I32, I32, F32, F32, P, P, P, P, P],
+    "sa_bn_finalize": [P, I64, I32, I32, I32, F32, F32, P, P, P, P, P],
     "sa_matmul_f32": [P, I64, I64, P, I64, I64, P, I64, I32, I32, I32, F32, P],
     "sa_bt_loss_grad": [P, I32, F32, F32, I32, P, P, P],
     "sa_adamw_step": [P, P, P, P, I64, F32, F32, F32, F32, F32, I32, F32, P, P],
     "sa_ema_update": [P, P, I64, F32, P],
     "sa_axpy_f32": [P, P, I64, F32, P],
+    "sa_count_nonfinite": [P, I64, P, P],
     "sa_logmel_fwd": [P, I64, I32, I32, P, P, P, P, P, P, I64, I32, I32, F32, F32, I32, P],
     "sa_augment_views": [P, I64, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, F32, I32, P],
     "sa_normalize_batch": [P, P, I64, F32, P, F32, P],

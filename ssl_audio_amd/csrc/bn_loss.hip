@@ -30,19 +30,20 @@ __global__ void bn_colstats_kernel(const float* __restrict__ x, int64_t ld, int 
 }
 
 // ---- combine per-rank (mean, M2) (Chan et al., equal row counts), produce mean / rstd and update the running buffers
-// stats: [W][2][C] (rank-major; [r][0] = mean_r, [r][1] = M2_r).  running_var uses the unbiased variance (PyTorch).
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int W, int rows_per_rank, int C, float eps, float momentum,
+// stats: [W][2][C] (rank-major; [r][0] = mean_r, [r][1] = M2_r), consecutive ranks rank_stride elements apart (several
+// tensors' statistics packed into ONE all-gather).  running_var uses the unbiased variance (PyTorch).
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int64_t rank_stride, int W, int rows_per_rank, int C, float eps, float momentum,
                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean = 0.f;
-  for (int r = 0; r < W; ++r) mean += stats[((int64_t)r * 2) * C + c];
+  for (int r = 0; r < W; ++r) mean += stats[r * rank_stride + c];
   mean /= (float)W;
   float m2 = 0.f;
   for (int r = 0; r < W; ++r) {
-    const float d = stats[((int64_t)r * 2) * C + c] - mean;
-    m2 += stats[((int64_t)r * 2 + 1) * C + c] + (float)rows_per_rank * d * d;
+    const float d = stats[r * rank_stride + c] - mean;
+    m2 += stats[r * rank_stride + C + c] + (float)rows_per_rank * d * d;
   }
   const float n = (float)W * (float)rows_per_rank;
   mean_out[c] = mean;
@@ -275,10 +276,11 @@ extern "C" int sa_bn_colstats(const float* x, int64_t ld, int32_t B, int32_t C, 
   return 0;
 }
 
-extern "C" int sa_bn_finalize(const float* stats, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum, float* mean,
-                              float* rstd, float* running_mean, float* running_var, void* stream) {
-  SA_CHECK_ARG(stats && mean && rstd && W > 0 && rows_per_rank > 0 && C > 0, "sa_bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, W, rows_per_rank, C, eps, momentum,
+extern "C" int sa_bn_finalize(const float* stats, int64_t rank_stride, int32_t W, int32_t rows_per_rank, int32_t C, float eps, float momentum,
+                              float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
+  if (rank_stride == 0) rank_stride = 2 * (int64_t)C;
+  SA_CHECK_ARG(stats && mean && rstd && W > 0 && rows_per_rank > 0 && C > 0 && rank_stride >= 2 * (int64_t)C, "sa_bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, rank_stride, W, rows_per_rank, C, eps, momentum,
                      mean, rstd, running_mean, running_var);
   SA_LAUNCH_CHECK("sa_bn_finalize");
   return 0;
@@ -368,6 +370,22 @@ extern "C" int sa_ema_update(float* target, const float* online, int64_t n, floa
   if (n == 0) return 0;
   hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta);
   SA_LAUNCH_CHECK("sa_ema_update");
+  return 0;
+}
+
+// flag[0] += number of non-finite values among x[0..n) (a handful of loss scalars; one wave)
+__global__ void count_nonfinite_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag) {
+  int bad = 0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) bad += !isfinite(x[i]);
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+  if (threadIdx.x == 0 && bad) atomicAdd(flag, bad);
+}
+
+extern "C" int sa_count_nonfinite(const float* x, int64_t n, int32_t* flag, void* stream) {
+  SA_CHECK_ARG(x && flag && n >= 0, "sa_count_nonfinite: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, n, flag);
+  SA_LAUNCH_CHECK("sa_count_nonfinite");
   return 0;
 }
 

@@ -328,6 +328,13 @@ extern "C" int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride,
   return 0;
 }
 
+extern "C" int sa_mae_recon_loss_finalize(const float* acc2, float* loss, void* stream) {
+  SA_CHECK_ARG(acc2 && loss, "sa_mae_recon_loss_finalize: bad args");
+  hipLaunchKernelGGL(mae_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc2, loss);
+  SA_LAUNCH_CHECK("sa_mae_recon_loss_finalize");
+  return 0;
+}
+
 extern "C" int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
                                      int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream) {
   SA_CHECK_ARG(pred && img && mask && acc2 && gscale && dpred && B > 0 && ph > 0 && pw > 0 && F % ph == 0 && T % pw == 0 && pred_row0 >= 0 &&

@@ -13,6 +13,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.nn as nn
 
 
 def is_dist_avail_and_initialized():
@@ -86,3 +87,71 @@ def all_reduce_sum_(t):
     if collectives_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+class GradSumParallel(nn.Module):
+    """What DistributedDataParallel is to the reference's drivers (utils/utils.py:412-416, applied main_bt_byol.py:440-444): the
+    wrapper `model_setup_ddp` returns.  `.module` is the wrapped network (state_dict keys carry the same "module." prefix DDP
+    gives the reference's checkpoints, main_bt_byol.py:494); forward delegates.  After every backward pass the gradients of
+    the wrapped parameters are SUMMED over ranks -- summed, not averaged: losses here are global-batch exact (every rank holds
+    the loss of the global batch and back-propagates its own rows' share of it).
+
+    Mechanics: a post-accumulate hook per parameter collects ready gradients into buckets of `bucket_bytes`; a full bucket is
+    flattened and all-reduced asynchronously on a side stream (RCCL) while the backward goes on; a callback queued on the
+    autograd engine for the end of the pass flushes the last bucket, joins the stream and scatters the sums back into `.grad`.
+    One backward per optimiser step, like DDP without no_sync().
+    """
+
+    def __init__(self, module, bucket_bytes=64 << 20):
+        super().__init__()
+        self.module = module
+        self.bucket_bytes = bucket_bytes
+        self._pending, self._pending_bytes, self._inflight, self._armed = [], 0, [], False
+        self._stream = None
+        for p in module.parameters():
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def _on_grad(self, p):
+        if not collectives_active() or p.grad is None:
+            return
+        if not self._armed:
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+            self._armed = True
+        self._pending.append(p)
+        self._pending_bytes += p.grad.numel() * p.grad.element_size()
+        if self._pending_bytes >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        params, self._pending, self._pending_bytes = self._pending, [], 0
+        if not params:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        if flat.is_cuda and dist.get_backend() == "nccl":
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._inflight.append((flat, params, work))
+
+    def _finish(self):
+        self._launch()
+        for flat, params, work in self._inflight:
+            work.wait()
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        for flat, params, _ in self._inflight:
+            off = 0
+            for p in params:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._inflight.clear()
+        self._armed = False

@@ -38,14 +38,19 @@ class _Bf16Cache:
         self._manual[id(p)] = self._manual.get(id(p), 0) + 1
 
     def pin(self, p, w16):
-        """`w16` (a view of train.FlatState's bf16 buffer) is kept current by the optimiser kernel: always use it."""
-        self._pinned[id(p)] = (w16, p.data_ptr(), weakref.ref(p))
+        """`w16` (a view of train.FlatState's bf16 buffer) is kept current by the optimiser kernel, whose in-place writes do not
+        touch torch's version counter.  Anything that DOES bump it (load_state_dict, an in-place torch op on the parameter)
+        changed the master behind the optimiser's back: the copy is re-cast on the next use."""
+        self._pinned[id(p)] = [w16, p.data_ptr(), weakref.ref(p), p._version]
 
     def get(self, p):
         # id() values are recycled once a parameter dies, so every entry carries a weak reference to ITS parameter
         key = id(p)
         pinned = self._pinned.get(key)
         if pinned is not None and pinned[2]() is p and pinned[1] == p.data_ptr():
+            if pinned[3] != p._version:
+                ops.cast_bf16(p.detach().reshape(pinned[0].shape), pinned[0])
+                pinned[3] = p._version
             return pinned[0]
         ent = self._c.get(key)
         ver = (p._version, self._manual.get(key, 0))
@@ -63,9 +68,29 @@ BF16_WEIGHTS = _Bf16Cache()
 # sink, the backward kernels accumulate straight into it and autograd is handed None (no per-parameter allocation,
 # no autograd accumulate pass, and the flat buffer is what the gradient all-reduce and the fused AdamW consume).
 GRAD_SINK = {}
-# called as BLOCK_DONE_HOOK(params_of_block) after each transformer block's backward (dp.GradSync overlaps the
-# gradient all-reduce of that block with the remaining backward)
+# called as BLOCK_DONE_HOOK(params_of_block) once a transformer block's gradients are FINAL (train.GradSync overlaps the
+# gradient all-reduce of that block with the remaining backward).  A block can be visited by several encoder passes of one
+# step (mode 'mae': masked view 1 and unmasked view 2; MultiCropWrapper with two crop widths): every forward pass that will
+# be differentiated arms one pending backward per block, and the hook fires when the LAST of them has run.
 BLOCK_DONE_HOOK = None
+_PENDING_BWD = {}
+
+
+def reset_pending_backward():
+    """Forget armed passes (start of a step: a forward whose backward never ran must not hold a block's all-reduce back)."""
+    _PENDING_BWD.clear()
+
+
+# id(q_bias) -> (weakref(q_bias), [3d] view [q_bias | 0 | v_bias]) when train.FlatState laid the two biases out around a zero
+# pad (the qkv GEMM's bias vector with the k-bias fixed at zero, models/mae.py:125-128) -- otherwise it is assembled per call
+QKV_BIAS = {}
+
+
+def qkv_bias(qb, vb):
+    ent = QKV_BIAS.get(id(qb))
+    if ent is not None and ent[0]() is qb and ent[1].data_ptr() == qb.data_ptr():
+        return ent[1]
+    return torch.cat((qb.detach(), torch.zeros_like(vb), vb.detach()))
 
 
 def grad_target(p):
@@ -115,8 +140,7 @@ def block_forward(x, p, H, N, eps, save):
     mean1, rstd1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
     ops.layernorm_fwd(x, p.n1w, p.n1b, eps, y_bf16=h1, mean=mean1, rstd=rstd1)
     qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
-    qkv_bias = torch.cat((p.qb.detach(), torch.zeros_like(p.vb), p.vb.detach()))  # k-bias is identically zero
-    ops.gemm(h1, W(p.wqkv), bias=qkv_bias, out_bf16=qkv)
+    ops.gemm(h1, W(p.wqkv), bias=qkv_bias(p.qb, p.vb), out_bf16=qkv)        # k-bias is identically zero
     ao = torch.empty(M, d, dtype=BF16, device=dev)
     lse = torch.empty(M // N * H, N, device=dev)
     ops.attention_fwd(qkv, H, N, (d // H) ** -0.5, ao, lse)
@@ -199,8 +223,7 @@ def block_forward_cls(x, p, H, N, eps, save):
     mean1, rstd1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
     ops.layernorm_fwd(x, p.n1w, p.n1b, eps, y_bf16=h1, mean=mean1, rstd=rstd1)
     qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
-    qkv_bias = torch.cat((p.qb.detach(), torch.zeros_like(p.vb), p.vb.detach()))
-    ops.gemm(h1, W(p.wqkv), bias=qkv_bias, out_bf16=qkv)
+    ops.gemm(h1, W(p.wqkv), bias=qkv_bias(p.qb, p.vb), out_bf16=qkv)
     ao = torch.zeros(M, d, dtype=BF16, device=dev)            # only the CLS rows are written
     lse = torch.zeros(S * H, N, device=dev)
     ops.attention_fwd(qkv, H, N, (d // H) ** -0.5, ao, lse, n_query=1)
@@ -294,6 +317,10 @@ class EncoderFn(torch.autograd.Function):
                 ops.mean_tokens_fwd(y.view(S, N, d), out)
             else:
                 out = y.view(S, N, d)
+        if need_grad and BLOCK_DONE_HOOK is not None:
+            for i in range(n_blocks):
+                key = id(params[13 * i + 2])
+                _PENDING_BWD[key] = _PENDING_BWD.get(key, 0) + 1
         ctx.cfg = (S, N, d, H, pool, n_blocks, cls_prune)
         ctx.saved = save
         ctx.final = (x, mean, rstd)
@@ -347,7 +374,12 @@ class EncoderFn(torch.autograd.Function):
                 dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i], b2_done=(i < n_blocks - 1), prev_b2=prev_b2)
             ctx.saved[i] = None
             if BLOCK_DONE_HOOK is not None:
-                BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])
+                key = id(params[13 * i + 2])
+                left = _PENDING_BWD.get(key, 1) - 1
+                _PENDING_BWD[key] = left
+                if left <= 0:
+                    _PENDING_BWD.pop(key, None)
+                    BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])
         dtok = dx.view(S, N, d) if ctx.needs_input_grad[0] else None
         return (dtok, None, None, None, None, *grads)
 

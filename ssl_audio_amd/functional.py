@@ -88,6 +88,7 @@ class MaeUnshuffleFn(torch.autograd.Function):
 
 class MaeReconLossFn(torch.autograd.Function):
     """forward_loss (models/mae.py:437-453) with patchify folded in: masked mean of the per-patch MSE.  One input channel.
+    Data parallel: the mean is over the GLOBAL batch's masked patches (acc2 is all-reduced), like every other term of the loss.
     `pred` is decoder_pred's full output [B, row0 + L, P]; row0 = 1 skips its CLS row in place (models/mae.py:433)."""
 
     @staticmethod
@@ -98,6 +99,9 @@ class MaeReconLossFn(torch.autograd.Function):
         acc2 = torch.empty(2, device=pred.device)
         loss = torch.empty((), device=pred.device)
         ops.mae_recon_loss_fwd(pred, row0, imgs, mask, ph, pw, acc2, loss.view(1))
+        if sdist.collectives_active():             # global masked mean: (sum of masked errors, mask count) summed over ranks
+            sdist.all_reduce_sum_(acc2)
+            ops.mae_recon_loss_finalize(acc2, loss.view(1))
         ctx.save_for_backward(pred, imgs, mask, acc2)
         ctx.cfg = (ph, pw, row0)
         return loss
@@ -166,7 +170,7 @@ def _bn_forward_stats(h, eps, running_mean, running_var):
     ops.bn_colstats(h, stats[0], stats[1])
     allst = sdist.all_gather_rows(stats)
     mean, rstd = torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)
-    ops.bn_finalize(allst.contiguous(), B, eps, BN_MOMENTUM, mean, rstd, running_mean, running_var)
+    ops.bn_finalize(allst, B, eps, BN_MOMENTUM, mean, rstd, running_mean, running_var)
     return mean, rstd
 
 
@@ -221,27 +225,32 @@ class MlpBnReluFn(torch.autograd.Function):
 class BTLossFn(torch.autograd.Function):
     """forward_loss(z1, z2) (utils/loss.py:15-30), fp32.  Data-parallel semantics: BN statistics and the
     cross-correlation are those of the GLOBAL batch; `literal_ddp=True` reproduces the reference's
-    per-rank BN + division by the local batch + SUM all-reduce instead."""
+    per-rank BN + division by the local batch + SUM all-reduce instead.
+
+    Exchanges per loss term (global-exact mode), each ONE collective:
+      forward   all-gather of the packed per-rank statistics [z1: mean, M2 | z2: mean, M2]  (4*D floats per rank)
+                all-reduce SUM of the D x D cross-correlation partials                     (utils/loss.py:20-21)
+      backward  all-reduce SUM of the packed BatchNorm backward sums [z1: s1, s2 | z2: s1, s2] (4*D floats)
+    """
 
     @staticmethod
     def forward(ctx, z1, z2, alpha, lmbda, hsic, running_mean, running_var, literal_ddp):
         B, D = z1.shape
         dev = z1.device
         W = sdist.get_world_size()
-        z1, z2 = z1.contiguous().float(), z2.contiguous().float()
-        norm, stats = [], []
-        for z in (z1, z2):                                   # bn(z1) then bn(z2): running stats see both, in this order
-            if literal_ddp and W > 1:
-                st = torch.empty(2, D, device=dev)
-                ops.bn_colstats(z, st[0], st[1])
-                mean, rstd = torch.empty(D, device=dev), torch.empty(D, device=dev)
-                ops.bn_finalize(st.unsqueeze(0), B, BN_EPS, BN_MOMENTUM, mean, rstd, running_mean, running_var)
-            else:
-                mean, rstd = _bn_forward_stats(z, BN_EPS, running_mean, running_var)
+        local_bn = bool(literal_ddp and W > 1)
+        z = (z1.contiguous().float(), z2.contiguous().float())
+        stats = torch.empty(2, 2, D, device=dev)                 # [view][mean | M2][D]
+        for v in range(2):
+            ops.bn_colstats(z[v], stats[v, 0], stats[v, 1])
+        allst = stats.unsqueeze(0) if local_bn else sdist.all_gather_rows(stats)        # [W, 2, 2, D]: one all-gather for both views
+        mean, rstd = torch.empty(2, D, device=dev), torch.empty(2, D, device=dev)
+        norm = []
+        for v in range(2):                                       # bn(z1) then bn(z2): running stats see both, in this order
+            ops.bn_finalize(allst[:, v], B, BN_EPS, BN_MOMENTUM, mean[v], rstd[v], running_mean, running_var)
             zn = torch.empty(B, D, device=dev)
-            ops.bn_apply(z, mean, rstd, None, None, False, y_f32=zn)
+            ops.bn_apply(z[v], mean[v], rstd[v], None, None, False, y_f32=zn)
             norm.append(zn)
-            stats.append((mean, rstd))
         n_eff = B if (literal_ddp or W == 1) else B * W
         c = torch.empty(D, D, device=dev)
         ops.matmul_f32(norm[0], norm[1], c, trans_a=True, alpha=1.0 / n_eff)
@@ -249,13 +258,13 @@ class BTLossFn(torch.autograd.Function):
         loss = torch.empty(1, device=dev)
         G = torch.empty(D, D, device=dev)
         ops.bt_loss_grad(c, alpha, lmbda, hsic, loss, G)
-        ctx.save_for_backward(z1, z2, norm[0], norm[1], stats[0][0], stats[0][1], stats[1][0], stats[1][1], G)
-        ctx.cfg = (n_eff, literal_ddp and W > 1)
+        ctx.save_for_backward(z[0], z[1], norm[0], norm[1], mean, rstd, G)
+        ctx.cfg = (n_eff, local_bn)
         return loss[0]
 
     @staticmethod
     def backward(ctx, dloss):
-        z1, z2, z1n, z2n, m1, r1, m2, r2, G = ctx.saved_tensors
+        z1, z2, z1n, z2n, mean, rstd, G = ctx.saved_tensors
         n_eff, local_bn = ctx.cfg
         B, D = z1.shape
         dev = z1.device
@@ -263,14 +272,15 @@ class BTLossFn(torch.autograd.Function):
         ops.matmul_f32(z2n, G, dz1n, trans_b=True, alpha=1.0 / n_eff)   # dz1n = z2n G^T / n
         ops.matmul_f32(z1n, G, dz2n, alpha=1.0 / n_eff)                  # dz2n = z1n G   / n
         scale = dloss.reshape(1).float().contiguous()
+        s = torch.empty(2, 2, D, device=dev)                             # [view][s1 | s2][D]: one all-reduce for both views
+        for v, (z, dzn) in enumerate(((z1, dz1n), (z2, dz2n))):
+            ops.bn_bwd_stats(dzn, z, mean[v], rstd[v], None, None, False, s[v, 0], s[v, 1])
+        if not local_bn:
+            sdist.all_reduce_sum_(s)
         outs = []
-        for z, dzn, mean, rstd in ((z1, dz1n, m1, r1), (z2, dz2n, m2, r2)):
-            s = torch.empty(2, D, device=dev)
-            ops.bn_bwd_stats(dzn, z, mean, rstd, None, None, False, s[0], s[1])
-            if not local_bn:
-                sdist.all_reduce_sum_(s)
+        for v, (z, dzn) in enumerate(((z1, dz1n), (z2, dz2n))):
             dz = torch.empty(B, D, device=dev)
-            ops.bn_bwd_apply(dzn, z, mean, rstd, None, None, False, s[0], s[1], 1.0 / (B if local_bn else n_eff), out_scale=scale,
+            ops.bn_bwd_apply(dzn, z, mean[v], rstd[v], None, None, False, s[v, 0], s[v, 1], 1.0 / (B if local_bn else n_eff), out_scale=scale,
                              dx_f32=dz)
             outs.append(dz)
         return outs[0], outs[1], None, None, None, None, None, None

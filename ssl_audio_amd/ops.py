@@ -68,7 +68,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
     a.row_group, a.split_k, a.accumulate, a.tile256 = row_group, split_k, int(accumulate), int(tile256)
     if colsum_out is not None:          # colsum_out[n] += sum_m (fp32 epilogue result)[m][n], through a scratch of per-64-row partials
-        ws = torch.empty(lib().sa_gemm_colsum_workspace_bytes(M, N) // 4, dtype=F32, device=A.device)
+        ws = _workspace(lib().sa_gemm_colsum_workspace_bytes(M, N), A.device, "gemm_colsum")
         a.colsum_out, a.colsum_ws = _req(colsum_out, F32, "colsum_out").data_ptr(), ws.data_ptr()
     if GEMM_PROFILE is None:
         check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
@@ -83,6 +83,20 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     nbytes = 2.0 * (M * K + N * K) + (4.0 * M * N if out_f32 is not None else 0.0) + (2.0 * M * N if out_bf16 is not None else 0.0) \
         + (2.0 * M * N if (aux_in is not None or aux_out is not None) else 0.0) + (4.0 * M * N if residual is not None and not res_mod else 0.0)
     GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes, kname))
+
+
+_WORKSPACES = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Grow-only scratch buffer per (device, tag): every launch that uses one is ordered on torch's current stream, so launches can
+    share it (no per-launch allocation: the step stays graph-capturable and free of allocator calls)."""
+    key = (device, tag)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
 
 
 CU_BUDGET = None      # CUs the big GEMM grids may use (None = the whole device); see set_cu_budget
@@ -160,7 +174,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=N
     lddres = _rows(dres, "dres")[2] if dres is not None else 0
     ws = None
     if dgamma is not None or dbeta is not None or dxsum is not None:      # scratch for the two-stage column reduction
-        ws = torch.empty(lib().sa_layernorm_bwd_workspace_bytes(M, D) // 4, dtype=F32, device=x.device)
+        ws = _workspace(lib().sa_layernorm_bwd_workspace_bytes(M, D), x.device, "ln_bwd")
     check(lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
                                  _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), _p(ws), M, D, _stream()), "sa_layernorm_bwd")
 
@@ -202,10 +216,12 @@ def bn_bwd_stats(dy, x, mean, rstd, gamma, beta, relu, s1, s2):
 
 
 def bn_finalize(stats, rows_per_rank, eps, momentum, mean, rstd, running_mean=None, running_var=None):
-    """stats: [W, 2, C] per-rank (mean, M2)."""
-    Wn, _, Cn = stats.shape
-    check(lib().sa_bn_finalize(_p(_req(stats, F32, "stats")), Wn, rows_per_rank, Cn, float(eps), float(momentum), _p(mean), _p(rstd),
-                               _p(running_mean), _p(running_var), _stream()), "sa_bn_finalize")
+    """stats: [W, 2, C] per-rank (mean, M2); may be a strided slice [:, k] of a packed [W, n, 2, C] all-gather."""
+    Wn, two, Cn = stats.shape
+    if two != 2 or stats.stride(2) != 1 or stats.stride(1) != Cn:
+        raise ValueError("bn_finalize: stats must be [W, 2, C] with contiguous (mean, M2) rows per rank")
+    check(lib().sa_bn_finalize(_p(_req(stats, F32, "stats")), stats.stride(0) if Wn > 1 else 0, Wn, rows_per_rank, Cn, float(eps), float(momentum),
+                               _p(mean), _p(rstd), _p(running_mean), _p(running_var), _stream()), "sa_bn_finalize")
 
 
 def bn_bwd_apply(dy, x, mean, rstd, gamma, beta, relu, s1, s2, inv_n, *, out_scale=None, dx_f32=None, dx_bf16=None):
@@ -254,6 +270,13 @@ def ema_update(target, online, beta):
 
 def axpy(y, x, a=1.0):
     check(lib().sa_axpy_f32(_p(_req(y, F32, "y")), _p(_req(x, F32, "x")), y.numel(), float(a), _stream()), "sa_axpy_f32")
+
+
+def count_nonfinite(x, flag):
+    """flag[0] (int32) += number of non-finite entries of the fp32 tensor x (no host synchronisation)."""
+    if flag.dtype != torch.int32:
+        raise TypeError("count_nonfinite: flag must be int32")
+    check(lib().sa_count_nonfinite(_p(_req(x, F32, "x")), x.numel(), _p(flag), _stream()), "sa_count_nonfinite")
 
 
 # ------------------------------------------------------------------------------------------------ frontend / augmentation
@@ -348,6 +371,10 @@ def mae_recon_loss_fwd(pred, row0, img, mask, ph, pw, acc2, loss):
     check(lib().sa_mae_recon_loss_fwd(_p(_req(pred, F32, "pred")), pred.shape[1] * pred.shape[2], row0, _p(_req(img, F32, "img")),
                                       _p(_req(mask, F32, "mask")), B, F_, T_, ph, pw, _p(_req(acc2, F32, "acc2")), _p(_req(loss, F32, "loss")),
                                       _stream()), "sa_mae_recon_loss_fwd")
+
+
+def mae_recon_loss_finalize(acc2, loss):
+    check(lib().sa_mae_recon_loss_finalize(_p(_req(acc2, F32, "acc2")), _p(_req(loss, F32, "loss")), _stream()), "sa_mae_recon_loss_finalize")
 
 
 def mae_recon_loss_bwd(pred, row0, img, mask, ph, pw, acc2, gscale, dpred):

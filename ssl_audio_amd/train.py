@@ -46,8 +46,23 @@ class FlatState:
                 decay.append((name, p))
         self.order = decay + nodecay + frozen
         pad8 = lambda n: (n + 7) // 8 * 8
+        # layout entries: (name, parameter, elements) -- parameter None = a zero pad.  Each attention's q_bias and v_bias are placed
+        # around a zero pad of the same length, so that [q_bias | 0 | v_bias] IS the qkv GEMM's bias vector (k-bias fixed at zero,
+        # models/mae.py:125-128) and no per-call assembly is needed.  The pad has zero gradient and no weight decay: AdamW leaves it 0.
+        by_name = dict(nodecay)
+        taken, nodecay_layout = set(), []
+        for name, p in nodecay:
+            if name in taken:
+                continue
+            sib = name[:-len("q_bias")] + "v_bias" if name.endswith(".q_bias") else None
+            if sib in by_name and p.numel() % 8 == 0 and by_name[sib].numel() == p.numel():
+                nodecay_layout += [(name, p, p.numel()), (None, None, p.numel()), (sib, by_name[sib], p.numel())]
+                taken.add(sib)
+            else:
+                nodecay_layout.append((name, p, p.numel()))
+        layout = [(n, p, p.numel()) for n, p in decay] + nodecay_layout + [(n, p, p.numel()) for n, p in frozen]
         self.n_decay = sum(pad8(p.numel()) for _, p in decay)
-        self.n_train = self.n_decay + sum(pad8(p.numel()) for _, p in nodecay)
+        self.n_train = self.n_decay + sum(pad8(n) for _, _, n in nodecay_layout)
         total = self.n_train + sum(pad8(p.numel()) for _, p in frozen)
         self.params = torch.zeros(total, device=device)
         self.params_bf16 = torch.zeros(total, dtype=torch.bfloat16, device=device)
@@ -55,14 +70,17 @@ class FlatState:
         self.m = torch.zeros(self.n_train, device=device)
         self.v = torch.zeros(self.n_train, device=device)
         self.offsets = {}
+        self.qkv_fused = {n for n, _, _ in nodecay_layout if n is not None and n.endswith(".q_bias") and n[:-len("q_bias")] + "v_bias" in taken}
         off = 0
-        for name, p in self.order:
-            n = p.numel()
-            self.params[off:off + n].copy_(p.detach().reshape(-1))
-            p.data = self.params[off:off + n].view(p.shape)
-            self.offsets[name] = (off, n)
-            if off < self.n_train:
-                engine.GRAD_SINK[id(p)] = (weakref.ref(p), self.grads[off:off + n].view(p.shape))
+        for name, p, n in layout:
+            if p is not None:
+                self.params[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.params[off:off + n].view(p.shape)
+                self.offsets[name] = (off, n)
+                if off < self.n_train:
+                    engine.GRAD_SINK[id(p)] = (weakref.ref(p), self.grads[off:off + n].view(p.shape))
+                if name in self.qkv_fused:
+                    engine.QKV_BIAS[id(p)] = (weakref.ref(p), self.params[off:off + 3 * n])
             off += pad8(n)
         ops.cast_bf16(self.params, self.params_bf16)
         self.bind_bf16()
@@ -120,7 +138,9 @@ class GradSync:
                 continue
             g = ent[1]
             a = (g.data_ptr() - self.flat.grads.data_ptr()) // 4
-            spans.append((a, a + (g.numel() + 7) // 8 * 8))
+            fused = engine.QKV_BIAS.get(id(p))                       # [q_bias | zero pad | v_bias]: one run, pad included
+            n = 3 * g.numel() if (fused is not None and fused[0]() is p) else g.numel()
+            spans.append((a, a + (n + 7) // 8 * 8))
         # a block's parameters sit in two places of the flat buffer (decayed weights | un-decayed vectors): reduce each
         # contiguous run on its own -- a single min..max range would sweep up other layers' unfinished gradients
         spans.sort()
@@ -207,6 +227,11 @@ class BarlowTwinsTrainer:
         self.post_norm = NormalizeBatch() if cfg.post_norm else None
         self.lr, self.wd = cfg.lr, cfg.wd
         self.last_loss = None
+        # main_bt_byol.py:116-118 stops on a non-finite loss with a host sync every step; here the test is a device-side counter that
+        # the host reads every `finite_check_every` steps (and whenever assert_finite() is called)
+        self._nonfinite = torch.zeros(1, dtype=torch.int32, device=device)
+        self.finite_check_every = 100
+        self._steps = 0
 
     # ------------------------------------------------------------------ data path
     def make_views(self, batch):
@@ -230,6 +255,7 @@ class BarlowTwinsTrainer:
     def step_views(self, views):
         """One optimisation step on two already-augmented views [B,1,F,T] (what train_one_epoch receives from its loader)."""
         self.flat.zero_grad()
+        engine.reset_pending_backward()
         if self.mode == "bt":
             z = self.online(views, ncrops=2)
             z1, z2 = z.chunk(2)
@@ -246,6 +272,7 @@ class BarlowTwinsTrainer:
                 t = self.target(views, ncrops=2)
             loss = self.criterion(o, t, ngcrops_each=2)
             self.flat_target.ema_from(self.flat, self.ema_beta)      # before the optimiser step (main_bt_byol.py:121-126)
+        ops.count_nonfinite(loss.detach().reshape(1), self._nonfinite)
         loss.backward()
         self.sync.finish()
         self.flat.adamw(self.lr, self.wd)
@@ -253,7 +280,17 @@ class BarlowTwinsTrainer:
             self.sync_pred.finish()
             self.flat_pred.adamw(self.lr, self.wd)
         self.last_loss = loss.detach()
+        self._steps += 1
+        if self._steps % self.finite_check_every == 0:
+            self.assert_finite()
         return self.last_loss
+
+    def assert_finite(self):
+        """Raises FloatingPointError if any step since the last call produced a non-finite loss (one host read of the device flag)."""
+        bad = int(self._nonfinite.item())
+        if bad:
+            self._nonfinite.zero_()
+            raise FloatingPointError(f"Loss was not finite in {bad} step(s). Stopping training (main_bt_byol.py:116-118)")
 
 
 class _FrozenFlat:
@@ -270,6 +307,8 @@ class _FrozenFlat:
             p.data = self.params[off:off + n].view(p.shape)
             w = self.params_bf16[off:off + n]
             engine.BF16_WEIGHTS.pin(p, w.view(p.shape[0], -1) if p.dim() > 1 else w)
+            if name in like.qkv_fused:
+                engine.QKV_BIAS[id(p)] = (weakref.ref(p), self.params[off:off + 3 * n])
         ops.cast_bf16(self.params, self.params_bf16)
 
     ema_from = FlatState.ema_from

@@ -87,10 +87,13 @@ def init_distributed_mode(cfg):
 
 
 def model_setup_ddp(gpu, model):
-    """The reference converts BN to SyncBN and wraps in DistributedDataParallel.  Here both are already built in:
-    the head's BN exchanges statistics itself (functional.MlpBnReluFn) and gradients are summed by dp.GradSync,
-    so this returns the module unchanged, keeping the (wrapped, unwrapped) return shape."""
-    return model, model
+    """utils/utils.py:410-417: the reference converts BN to SyncBN and wraps the network in DistributedDataParallel.
+    Here SyncBN is built in (functional.MlpBnReluFn exchanges the BatchNorm statistics itself), and the wrapper returned is
+    dist.GradSumParallel: after each backward it all-reduces (SUM: the loss is global-batch exact) the wrapped parameters'
+    gradients in buckets on a side stream, so the driver's own optimizer (torch.optim.AdamW, main_bt_byol.py:302-313) steps
+    on global gradients and the replicas stay identical.  Returns (wrapper, wrapped) like the reference."""
+    wrapped = sdist.GradSumParallel(model)
+    return wrapped, wrapped.module
 
 
 def save_on_master(*args, **kwargs):

@@ -106,6 +106,131 @@ def test_two_ranks_equal_single_process():
         np.testing.assert_array_equal(res[0][2][k], res[1][2][k])        # replicas stay bit-identical across ranks
 
 
+# ------------------------------------------------------------------------------------------------ drop-in path + model_setup_ddp, trainer 'mae'
+def _dropin_step(rank, world):
+    """train_one_epoch's calls (main_bt_byol.py:79-135, --stop_gradient --predictor) on the drop-in classes with the driver's own
+    optimizer (torch.optim.AdamW on .grad), networks wrapped by utils.model_setup_ddp as main_bt_byol.py:440-444 does."""
+    from ssl_audio_amd import hyperparameters as hp, model, utils
+    from ssl_audio_amd.loss import BarlowTwinsLoss
+    dev = torch.device("cuda:0")
+    Bg = 16
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=Bg, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       stop_gradient=True, predictor=True)
+    torch.manual_seed(0)
+    online = utils.MultiCropWrapper(model.ModelWrapper(cfg), model.BarlowTwinsHead(cfg, 192)).to(dev)
+    predictor = model.BarlowTwinsPredictor(128, use=True).to(dev)
+    target = utils.MultiCropWrapper(model.ModelWrapper(cfg), model.BarlowTwinsHead(cfg, 192)).to(dev)
+    target.load_state_dict(online.state_dict())
+    for p in target.parameters():
+        p.requires_grad = False
+    online_ddp, online = utils.model_setup_ddp(0, online)
+    pred_ddp, predictor = utils.model_setup_ddp(0, predictor)
+    online_ddp.bucket_bytes = 4 << 20                       # several buckets on ViT-T (22 MB of gradients)
+    crit = BarlowTwinsLoss(cfg, ncrops=2).to(dev)
+    opt = torch.optim.AdamW(utils.get_param_groups(online) + utils.get_param_groups(predictor), lr=cfg.lr, weight_decay=cfg.wd)
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(Bg, 1, 64, 96, generator=g)
+    views = [base + 0.3 * torch.randn(Bg, 1, 64, 96, generator=g), base + 0.3 * torch.randn(Bg, 1, 64, 96, generator=g)]
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    images = [v[sl].to(dev).contiguous() for v in views]
+    p0 = {k: v.detach().float().cpu().numpy().copy() for k, v in online.state_dict().items() if k in KEYS}
+    o = online_ddp(images[:2], ncrops=2)
+    o = pred_ddp(o, ncrops=1)
+    t = target(images, ncrops=2)
+    loss = crit(o, t, ngcrops_each=2)
+    utils.update_moving_average(utils.EMA(0.99), target, online)
+    opt.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(online.named_parameters())
+    grads = {k: named[k].grad.detach().float().cpu().numpy().copy() for k in KEYS if k in named}
+    grads["predictor.0.weight"] = predictor.predictor[0].weight.grad.detach().float().cpu().numpy().copy()
+    opt.step()
+    torch.cuda.synchronize()
+    sd = online.state_dict()
+    return float(loss.detach()), {k: sd[k].detach().float().cpu().numpy() for k in KEYS}, grads, p0, cfg.lr
+
+
+def _mae_step(rank, world):
+    """trainer 'mae' (BASELINE config 5's flow): the encoder blocks are visited by TWO passes per step (masked view 1, unmasked
+    view 2), so a block's gradient range may be all-reduced only after the second pass (engine pending-backward counters), and the
+    reconstruction loss is the masked mean over the GLOBAL batch."""
+    from ssl_audio_amd import hyperparameters as hp
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    dev = torch.device("cuda:0")
+    Bg = 16
+    g = torch.Generator().manual_seed(3)
+    mask = torch.zeros(Bg, 24)
+    for b in range(Bg):
+        mask[b, torch.randperm(24, generator=g)[:18]] = 1
+    views = [torch.randn(Bg, 1, 64, 96, generator=g), torch.randn(Bg, 1, 64, 96, generator=g)]
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=Bg, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       masked_recon=True, mask=True, mask_ratio=mask[sl].to(dev))
+    tr = BarlowTwinsTrainer(cfg, dev, mode="mae", batch_per_rank=Bg // world, clip_samples=15200, seed=0, from_waveform=False)
+    p0 = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.online.state_dict().items() if k in KEYS}
+    loss = float(tr.step_views([v[sl].to(dev).contiguous() for v in views]))
+    torch.cuda.synchronize()
+    from ssl_audio_amd import engine
+    named = dict(tr.online.named_parameters())
+    extra = ["backbone.encoder.encoder.decoder_blocks.0.attn.qkv.weight", "backbone.encoder.encoder.mask_token",
+             "backbone.encoder.encoder.decoder_pred.weight", "backbone.encoder.encoder.blocks.5.mlp.fc1.weight"]
+    grads = {k: engine.GRAD_SINK[id(named[k])][1].detach().float().cpu().numpy().copy() for k in KEYS + extra if k in named}
+    sd = tr.online.state_dict()
+    return loss, {k: sd[k].detach().float().cpu().numpy() for k in KEYS}, grads, p0, tr.lr
+
+
+_STEPS = {"dropin": _dropin_step, "mae": _mae_step}
+
+
+def _worker2(kind, rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          SA_DIST_BACKEND="gloo")
+        from ssl_audio_amd import dist as sdist
+        sdist.init_from_env("gloo")
+        out = _STEPS[kind](rank, world)
+        q.put((rank, None) + tuple(out))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("kind", ["dropin", "mae"])
+def test_two_ranks_equal_single_process_other_flows(kind):
+    """(dropin) the reference driver's own loop on the drop-in classes, wrapped by utils.model_setup_ddp, torch.optim.AdamW;
+    (mae) trainer mode 'mae'.  Two ranks with half of the batch each == one process on the whole batch: same loss, summed
+    gradients equal the single-process gradients (3e-2: bf16 partial sums in another order), replicas bit-identical."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2, args=(kind, r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] is None, r[1]
+    loss, sd, g_ref, p0, lr = _STEPS[kind](0, 1)
+    for r in res:
+        assert abs(r[2] - loss) / abs(loss) < 3e-3, (r[2], loss)
+        for k, g in g_ref.items():
+            err = np.linalg.norm(r[4][k] - g) / (np.linalg.norm(g) + 1e-30)
+            assert err < 3e-2, (kind, k, err)
+    assert abs(res[0][2] - res[1][2]) < 1e-6 * abs(loss) + 1e-6
+    for k in KEYS:
+        np.testing.assert_array_equal(res[0][3][k], res[1][3][k])        # replicas stay bit-identical across ranks
+        if "running" not in k:
+            moved = np.abs(sd[k] - p0[k]).max()
+            assert 0 < moved <= 1.01 * lr + 1e-9, (k, moved)
+            assert np.mean(np.abs(res[0][3][k] - sd[k]) <= 0.25 * lr) > 0.7, k
+
+
 def test_rccl_call_sites_with_one_rank():
     """The driver's multi-GPU launch (`torch.distributed.run ... bench.py --gpus N`, backend nccl = RCCL) rehearsed with one
     rank: SA_DIST_FORCE=1 makes every collective call site really issue its RCCL call (all-gather of BN statistics, all-reduce

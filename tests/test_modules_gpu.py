@@ -249,12 +249,24 @@ def test_full_step_golden(dev, golden, tag, stop_grad, use_pred):
         loss.backward()
         if it == 0:
             named = dict(online.named_parameters())
-            errs = {k[len("grad0."):]: rel(named[k[len("grad0."):]].grad, g[k]) for k in g if k.startswith("grad0.")}
-            print("first-step gradient rel errors:", {k: round(v, 4) for k, v in errs.items()})
-            # These B=8 fixtures are bf16-hostile (BatchNorm over 8 rows feeding a correlation loss): rounding ONLY the
-            # matmul operands to bf16 in PyTorch's own CPU autocast moves these gradients by 0.11-0.18 relative
-            # (scripts/diag_bf16_sensitivity.py).  The bound below is that measured sensitivity with 2x margin.
-            assert max(errs.values()) < 0.35, errs
+            errs_fp32 = {k[len("grad0."):]: rel(named[k[len("grad0."):]].grad, g[k]) for k in g if k.startswith("grad0.")}
+            # Against the reference's fp32 gradients the distance is the fixture's bf16 sensitivity (0.1-0.25), which by itself
+            # cannot tell a wrong kernel from a right one.  The discriminating check (tests/gradcheck.py) bounds the distance to
+            # the oracle in bf16-mirror mode by 3x that measured sensitivity per parameter and demands cosine >= 0.9 on every
+            # weight matrix; the tight 2e-2 bound lives in test_configs_gpu.py::test_cfg3_encoder_gradients_linear_loss.
+            from gradcheck import check_step_gradients
+            from oracle import rounding as R, step as ostep
+
+            def oracle_grads(mirror):
+                osd = {k[len("online_sd."):]: T(v) for k, v in g.items() if k.startswith("online_sd.")}
+                psd = {k[len("pred_sd."):]: T(v) for k, v in g.items() if k.startswith("pred_sd.")}
+                with R.mirror_hip_bf16(mirror):
+                    return ostep.bt_byol_step(osd, {k: v.clone() for k, v in osd.items()}, psd, [T(g["view0"]), T(g["view1"])], 2, (4, 6),
+                                              ostep.AdamW(float(g["lr"]), float(g["wd"])), stop_grad, use_pred)[1]
+
+            print("first-step gradient rel errors vs the reference's fp32 gradients:", {k: round(v, 4) for k, v in errs_fp32.items()})
+            check_step_gradients(f"step_{tag}", {k: p.grad for k, p in named.items() if p.grad is not None}, oracle_grads(True), oracle_grads(False), 25)
+            assert max(errs_fp32.values()) < 0.35, errs_fp32
         opt.step()
     np.testing.assert_allclose(losses, g["losses"], rtol=3e-2)
     sd = online.state_dict()
@@ -378,12 +390,17 @@ def test_main_py_local_crops_vs_oracle(dev, golden):
     assert rel(teacher, zt) < 2e-2 and rel(student, zs) < 2e-2          # bf16 GEMM operands through 2 blocks + projector
     assert abs(float(loss) - float(ref)) / abs(float(ref)) < 3e-2
     named = dict(net.named_parameters())
-    errs = {k: rel(named[k].grad, gr) for k, gr in zip(names, gref) if gr is not None and float(gr.norm()) > 1e-3 and named[k].grad is not None}
-    # (norm.bias is excluded by the 1e-3 floor: the bias-free projector + BatchNorm cancel it, its true gradient is 1e-5 of the others)
-    assert len(errs) > 20
-    # B = 5 rows under BatchNorm + a correlation loss is as bf16-hostile as the step fixtures (see test_full_step_golden)
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
-    assert sorted(errs.values())[len(errs) // 2] < 0.15 and max(errs.values()) < 0.5, worst
+    # gradients: HIP vs the same oracle in bf16-mirror mode, bounded by 3x the fixture's measured bf16 sensitivity (tests/gradcheck.py)
+    from gradcheck import check_step_gradients
+    from oracle import rounding as R
+    with R.mirror_hip_bf16():
+        zt, _ = ostep.network_forward(leaf, cpu[:1], 1, 2, (4, 6))
+        zs, _ = ostep.network_forward(leaf, cpu[1:], L + 1, 2, (4, 6))
+        mref, _ = oheads.bt_forward(zs, zt, L + 2, ngcrops_each=1)
+        gmir = torch.autograd.grad(mref, [leaf[k] for k in names], allow_unused=True)
+    print("local crops: loss", float(loss), "oracle", float(ref), "mirror", float(mref))
+    check_step_gradients("local crops", {k: named[k].grad for k in names if named[k].grad is not None},
+                         {k: gr for k, gr in zip(names, gmir) if gr is not None}, {k: gr for k, gr in zip(names, gref) if gr is not None}, 20)
 
 
 # ------------------------------------------------------------------------------------------------ MixGaussianNoise, RunningNorm
