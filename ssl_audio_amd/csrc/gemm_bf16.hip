@@ -9,437 +9,11 @@
 // and wgrad (TN) are the same kernel and no transposed copy of a weight or activation is ever made.
 // LDS destination of an LDS-DMA is lane-linear, so swizzles are applied to the per-lane SOURCE address
 // and again on the fragment read (cdna_hip_programming.md rule 21).
-#include <stdlib.h>
-#include <type_traits>
-#include "common.h"
-#include "../../include/ssl_audio_hip.h"
+#include "gemm_common.h"
+
+int sagemm::g_cu_budget = 0;
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
-constexpr int NTHREADS = 256;
-
-// CUs the persistent kernels may occupy (0 = all).  Under data parallelism RCCL's collective kernels hold a few CUs for the
-// length of an all-reduce; a persistent grid sized to the whole chip would then run its last workgroups as a second wave and
-// take twice as long, so the host reserves those CUs (sa_set_cu_budget) instead.
-int g_cu_budget = 0;
-inline int budget_slots(int cus, int per_cu = 1) {
-  const int use = (g_cu_budget > 0 && g_cu_budget < cus) ? g_cu_budget : cus;
-  return use * per_cu;
-}
-
-struct GemmParams {
-  const char* A; const char* B;
-  uint32_t a_bytes, b_bytes;       // buffer extents for the hardware bounds check
-  int lda, ldb;
-  int M, N, K;
-  float alpha;
-  const float* bias;
-  int act;
-  const bf16_t* aux_in; bf16_t* aux_out; int64_t ldaux;
-  const float* residual; int64_t ldr; int res_mod;
-  float* out_f32; int64_t ldo_f32;
-  bf16_t* out_bf16; int64_t ldo_bf16;
-  int row_group;
-  int split_k; int accumulate;
-  int tiles_m, tiles_n;
-  int gm;   // row-panels per tile group (L2 locality knob)
-  int gm256;         // row-panels per tile group in the 256^2 kernels
-  int stagger;       // persistent 256^2 kernel: wave row 1 requests its LDS-DMA share mid-step
-  int ring_phase;    // ring kernel: requests phased by wave row
-  int epi_kind;      // 1..4: one of the compact epilogues applies (wave_epilogue_compact); 0: general epilogue
-  int nt_store;      // bf16 outputs with non-temporal stores
-  float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
-};
-
-// 16-byte-chunk XOR for a k-strided tile row: rows {0..3, 8..11} (one 32-lane half of a transposing
-// read) land on 8 distinct 32-byte slots of the 256-byte bank row.
-__device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
-
-// ---- HBM -> LDS staging of one operand tile ---------------------------------------------------------
-// k-major operand: tile = 128 rows x 64 k (128 B rows).  16 wave-instructions of 1 KiB (8 rows each).
-template <bool KMAJOR, int NWAVES = 4>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
-                                           int wave, int lane) {
-  constexpr int PER_WAVE = 16 / NWAVES;
-  if constexpr (KMAJOR) {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      const int q = wave * PER_WAVE + i;
-      const int row = q * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ (row & 7);
-      const uint32_t voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
-    }
-  } else {
-    // k-strided operand: tile = 64 k-rows x 128 cols (256 B rows).  16 wave-instructions (4 k-rows each).
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      const int q = wave * PER_WAVE + i;
-      const int krow = q * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ ks_swz(krow);
-      const uint32_t voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
-    }
-  }
-}
-
-// one wave-instruction (number q of 16) of stage_tile, with a validity flag: lets a kernel space its LDS-DMA requests out between
-// MFMAs; an invalid request goes out of range (zero fill, no traffic) so vmcnt bookkeeping stays exact
-template <bool KMAJOR>
-__device__ __forceinline__ void stage_one_v(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane, bool valid) {
-  uint32_t voff;
-  if constexpr (KMAJOR) {
-    const int row = q * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (row & 7);
-    voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
-  } else {
-    const int krow = q * 4 + (lane >> 4);
-    const int chunk = (lane & 15) ^ ks_swz(krow);
-    voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
-  }
-  voff = valid ? voff : 0xFFFFFFF0u;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
-}
-
-// ---- LDS -> register fragment for one 16-wide sub-tile and one 32-deep k-step -------------------------
-// Returns the 8 bf16 a lane feeds to v_mfma_f32_16x16x32_bf16: element j <-> k = 8*(lane>>4) + j, for
-// output index (row of A / column of B) sub0 + (lane & 15).
-template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int sub0, int kstep, int lane) {
-  if constexpr (KMAJOR) {
-    const int r = sub0 + (lane & 15);
-    const int kq = kstep * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((kq ^ (r & 7)) << 4));
-  } else {
-    const int i = lane & 15, g = lane >> 4;
-    const int krow = kstep * 32 + 8 * g + (i >> 2);
-    const int col = sub0 + 4 * (i & 3);
-    const int off = (((col >> 3) ^ ks_swz(krow)) << 4) + ((col >> 2) & 1) * 8;  // ks_swz(krow) == ks_swz(krow + 4)
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + krow * 256 + off));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_tile + (krow + 4) * 256 + off));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-  }
-}
-
-// ---- epilogue for one accumulator fragment: lane owns row m and columns n..n+3 (swapped MFMA operand order)
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4& a, int m, int n, int64_t orow, int64_t rrow) {
-  if (n >= p.N) return;
-  if (n + 3 >= p.N) {
-    for (int r = 0; r < 4 && n + r < p.N; ++r) {
-      float x = a[r] * p.alpha;
-      if (p.bias) x += p.bias[n + r];
-      if (p.act == 1 || p.act == 3) {
-        if (p.aux_out) p.aux_out[(int64_t)m * p.ldaux + n + r] = f2bf(p.act == 3 ? dgelu_f(x) : x);
-        x = gelu_f(x);
-      } else if (p.act == 2 || p.act == 4) {
-        const float h = bf2f(p.aux_in[(int64_t)m * p.ldaux + n + r]);
-        x *= p.act == 4 ? h : dgelu_f(h);
-      }
-      if (p.residual) x += p.residual[rrow * p.ldr + n + r];
-      if (p.out_f32) {
-        float* o = p.out_f32 + orow * p.ldo_f32 + n + r;
-        *o = p.accumulate ? *o + x : x;
-      }
-      if (p.out_bf16) p.out_bf16[orow * p.ldo_bf16 + n + r] = f2bf(x);
-    }
-    return;
-  }
-  float v[4] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha};
-  if (p.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-  if (p.act == 1 || p.act == 3) {
-    if (p.aux_out) {
-      bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      if (p.act == 3) h = bf16x4{f2bf(dgelu_f(v[0])), f2bf(dgelu_f(v[1])), f2bf(dgelu_f(v[2])), f2bf(dgelu_f(v[3]))};
-      *reinterpret_cast<bf16x4*>(p.aux_out + (int64_t)m * p.ldaux + n) = h;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-  } else if (p.act == 2 || p.act == 4) {
-    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= p.act == 4 ? bf2f(h[r]) : dgelu_f(bf2f(h[r]));
-  }
-  if (p.residual) {
-    const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
-    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-  }
-  if (p.out_f32) {
-    float* o = p.out_f32 + orow * p.ldo_f32 + n;
-    if (p.accumulate) {
-      const float4 old = *reinterpret_cast<const float4*>(o);
-      v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-    }
-    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-  if (p.out_bf16) {
-    bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    *reinterpret_cast<bf16x4*>(p.out_bf16 + orow * p.ldo_bf16 + n) = h;
-  }
-}
-
-// ---- wave-private staged epilogue for a 64 x 64 wave tile (acc[4][4], swapped operand order: lane = row c, cols 4g..)
-// A row-per-lane bf16 epilogue is 16 x 8-byte stores per lane, each instruction touching 16 rows x 32 B: the store
-// tail is ISSUE-bound (cdna_hip_programming.md T21).  Staging the tile through 9 KiB of this wave's LDS turns it
-// into 8 x 16-byte stores per lane that write whole 128-byte row segments.  fp32 outputs already store 16 B per lane.
-constexpr int EPI_STRIDE = 144;                 // bytes per staged row: 64 bf16 + 16 B pad (16-byte aligned rows)
-constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
-
-// SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by (row & 7),
-// exactly 8 KiB per wave -- four waves fit one 32 KiB pipeline stage (the persistent kernel stages its epilogue in the
-// stage it has just finished reading while the other stage already receives the next tile).
-template <bool SWZ, int XF = 0>   // XF = 1: store GELU'(v) and REPLACE v by GELU(v) (forward fc1 with act = 3; one exp + one rcp for both)
-__device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v)[4][4], char* wlds, bf16_t* dst, int64_t ld,
-                                                  int m_base, int n_base, bool remap, int lane) {
-  const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf16x4 h = {f2bf(v[i][j][0]), f2bf(v[i][j][1]), f2bf(v[i][j][2]), f2bf(v[i][j][3])};
-      if constexpr (XF == 1) {
-        float dy[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float y;
-          gelu_pair(v[i][j][r], y, dy[r]);
-          v[i][j][r] = y;
-        }
-        h = bf16x4{f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
-      }
-      const int row = i * 16 + c;
-      if constexpr (SWZ)
-        *reinterpret_cast<bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = h;
-      else
-        *reinterpret_cast<bf16x4*>(wlds + row * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
-    }
-  const int ch = lane & 7;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = it * 8 + (lane >> 3);
-    const int m = m_base + r;
-    const uint4 val = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
-                          : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
-    if (m < p.M) {
-      const int64_t orow = (remap && p.row_group > 0) ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-      if (p.nt_store == 2) {
-        asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));     // timing experiment: no global store at all
-      } else if (p.nt_store) {   // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels: streaming stores that do not displace the operands in L2
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dst + orow * ld + n_base + ch * 8));
-      } else {
-        *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
-      }
-    }
-  }
-}
-
-// Mirror of staged_store_bf16 for an epilogue INPUT: a row-per-lane read of aux_in touches 16 rows x 32 B per instruction (a quarter
-// of every 128-byte line it pulls in); going through the wave's LDS scratch reads whole 128-byte row segments instead.  Swizzled layout only.
-__device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds, const bf16_t* src, int64_t ld, int m_base, int n_base, int lane) {
-  const int ch = lane & 7;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = it * 8 + (lane >> 3);
-    const int m = m_base + r;
-    uint4 val = make_uint4(0u, 0u, 0u, 0u);
-    if (m < p.M) val = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + n_base + ch * 8);
-    *reinterpret_cast<uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4)) = val;
-  }
-}
-
-// Compact epilogues for the four combinations the ViT blocks use (whole 64-column block inside N, aligned outputs).  The general
-// epilogue below is thousands of instructions of mostly-untaken paths with spilled scalars; a once-per-tile walk through it was
-// measured at 15 k cycles per 256 x 256 tile even for a bias-only epilogue, against 9 k for the compact path.
-//   kind 1: alpha * acc + bias -> bf16                                   (qkv forward, every dgrad without an activation)
-//   kind 2: alpha * acc + bias -> aux_out (bf16), GELU -> bf16           (fc1 forward)
-//   kind 3: alpha * acc + bias + residual -> fp32                        (proj / fc2 forward)
-//   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad, act 2: aux holds the pre-activation)
-//   kind 5: alpha * acc * aux_in -> bf16 (+ column sums)                 (fc2 dgrad, act 4: aux already holds GELU')
-//   kind 6: alpha * acc + bias -> aux_out = GELU'(.), bf16 = GELU(.)     (fc1 forward, act 3)
-template <bool SWZ, int kind>
-__device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
-  if (n_base >= p.N) return;                    // N is a multiple of 64 here: a 64-column block is wholly inside or wholly outside
-  const int g = lane >> 4, c = lane & 15;
-  const float alpha = p.alpha;
-  if constexpr (kind != 4 && kind != 5) {   // (kinds 1, 2, 3, 6 start from alpha * acc + bias)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[i][j][0] = acc[i][j][0] * alpha + b.x; acc[i][j][1] = acc[i][j][1] * alpha + b.y;
-        acc[i][j][2] = acc[i][j][2] * alpha + b.z; acc[i][j][3] = acc[i][j][3] * alpha + b.w;
-      }
-    }
-  }
-  if constexpr (kind == 1) {
-    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
-  } else if constexpr (kind == 6) {          // fc1 forward, act 3: aux <- GELU'(v), acc <- GELU(v) in one pass, then the activation
-    staged_store_bf16<SWZ, 1>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
-    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
-  } else if constexpr (kind == 2) {
-    staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_f(acc[i][j][r]);
-      __builtin_amdgcn_sched_barrier(0);               // 16 activations at a time: 64 interleaved erf chains spill
-    }
-    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
-  } else if constexpr (kind == 3) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m_base + i * 16 + c;
-      if (m >= p.M) continue;
-      const float* rrow = p.residual + (int64_t)m * p.ldr + n_base + 4 * g;
-      float* orow = p.out_f32 + (int64_t)m * p.ldo_f32 + n_base + 4 * g;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 rv = *reinterpret_cast<const float4*>(rrow + j * 16);
-        *reinterpret_cast<float4*>(orow + j * 16) =
-            make_float4(acc[i][j][0] + rv.x, acc[i][j][1] + rv.y, acc[i][j][2] + rv.z, acc[i][j][3] + rv.w);
-      }
-    }
-  } else {
-    static_assert(SWZ, "the compact epilogues stage through the swizzled 8 KiB scratch");
-    staged_load_bf16(p, wlds, p.aux_in, p.ldaux, m_base, n_base, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + c;                       // rows past M were staged as zeros: their products are zero, nothing is stored
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * (kind == 5 ? bf2f(h[r]) : dgelu_f(bf2f(h[r])));
-      }
-    }
-    if (p.colsum_ws && m_base < p.M) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float cs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-          cs[r] = t;
-        }
-        if (c == 0) *reinterpret_cast<float4*>(p.colsum_ws + (int64_t)(m_base >> 6) * p.N + n_base + j * 16 + 4 * g) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-      }
-    }
-    staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
-  }
-}
-
-template <bool SWZ = false>
-__device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, char* wlds, int lane) {
-  const int g = lane >> 4, c = lane & 15;
-  const bool fast = (n_base + 64 <= p.N) &&
-                    (!p.out_bf16 || ((p.ldo_bf16 & 7) == 0 && ((uintptr_t)p.out_bf16 & 15) == 0)) &&
-                    (!p.aux_out || ((p.ldaux & 7) == 0 && ((uintptr_t)p.aux_out & 15) == 0));
-  if (!fast) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m_base + i * 16 + c;
-      if (m >= p.M) continue;
-      const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-      const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) epilogue_store(p, acc[i][j], m, n_base + j * 16 + 4 * g, orow, rrow);
-    }
-    return;
-  }
-  // v = alpha * acc + bias
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[i][j][0] = acc[i][j][0] * p.alpha + b.x; acc[i][j][1] = acc[i][j][1] * p.alpha + b.y;
-      acc[i][j][2] = acc[i][j][2] * p.alpha + b.z; acc[i][j][3] = acc[i][j][3] * p.alpha + b.w;
-    }
-  }
-  if (p.act == 3) {                                  // (act = 3 always comes with aux_out)
-    staged_store_bf16<SWZ, 1>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
-  } else if (p.act == 1) {
-    if (p.aux_out) staged_store_bf16<SWZ>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_f(acc[i][j][r]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m_base + i * 16 + c;
-    if (m >= p.M) continue;
-    const int64_t orow = p.row_group > 0 ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-    const int64_t rrow = p.res_mod > 0 ? (int64_t)(m % p.res_mod) : (int64_t)m;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n_base + j * 16 + 4 * g;
-      if (p.act == 2 || p.act == 4) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(p.aux_in + (int64_t)m * p.ldaux + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] *= p.act == 4 ? bf2f(h[r]) : dgelu_f(bf2f(h[r]));
-      }
-      if (p.residual) {
-        const float4 rv = *reinterpret_cast<const float4*>(p.residual + rrow * p.ldr + n);
-        acc[i][j][0] += rv.x; acc[i][j][1] += rv.y; acc[i][j][2] += rv.z; acc[i][j][3] += rv.w;
-      }
-      if (p.out_f32) {
-        float* o = p.out_f32 + orow * p.ldo_f32 + n;
-        if (p.accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(o);
-          acc[i][j][0] += old.x; acc[i][j][1] += old.y; acc[i][j][2] += old.z; acc[i][j][3] += old.w;
-        }
-        *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep each 16-row group's loads/stores together: hoisting all 16 residual loads spills
-  }
-  if (p.colsum_ws && m_base < p.M) {     // (a 64-row block wholly past M has no workspace row)
-    // column sums of this 64 x 64 block over its valid rows: 4 adds in registers, a 16-lane butterfly, one row of the workspace
-    float cs[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-        cs[j][r] = t;
-      }
-    if (c == 0) {
-      float* w = p.colsum_ws + (int64_t)(m_base >> 6) * p.N + n_base + 4 * g;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(w + j * 16) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
-    }
-  }
-  if (p.nt_store == 3) {                                 // timing experiment: no staging, no stores
-    asm volatile("" ::"v"(acc[0][0]), "v"(acc[3][3]), "v"(acc[1][2]), "v"(acc[2][1]));
-    return;
-  }
-  if (p.out_bf16) staged_store_bf16<SWZ>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, true, lane);
-}
 
 template <bool A_KM, bool B_KM, bool SWAP>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
@@ -1976,7 +1550,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream);
 
 extern "C" int sa_set_cu_budget(int32_t cus) {
   SA_CHECK_ARG(cus >= 0, "sa_set_cu_budget: negative CU count");
-  g_cu_budget = cus;
+  sagemm::g_cu_budget = cus;
   return 0;
 }
 
@@ -2081,6 +1655,14 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
   char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
   if (mode == '2' && p.colsum_ws) mode = '6';   // the plain 256^2 kernel has its own epilogue without the column-sum hook
+  if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4 && !(p.epi_kind == 5 && !p.colsum_ws && false)) {
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    const int rc = sagemm::launch_phase(p, a->a_kmajor, a->b_kmajor, false, stream);
+    if (rc >= 0) return rc;
+    mode = (a->a_kmajor && !a->b_kmajor) ? '8' : '6';
+  } else if (mode == 'A' && a->split_k == 1) {
+    mode = big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1';
+  }
   if (mode == '9' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     if (a->a_kmajor && a->b_kmajor) return launch256_early<true, true>(p, stream);
@@ -2131,6 +1713,9 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   }
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    static const char* wphase = getenv("SA_GEMM_WGRAD_PHASE");
+    if (wphase && wphase[0] == '1' && !a->a_kmajor && !a->b_kmajor && (a->K + BK - 1) / BK / a->split_k >= 2)
+      return sagemm::launch_phase(p, false, false, true, stream);
     static const char* wring = getenv("SA_GEMM_WGRAD_RING");
     if (wring && wring[0] == '1') {
       if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, true>(p, stream);
