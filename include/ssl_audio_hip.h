@@ -69,10 +69,6 @@ int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
  * the CUs RCCL's collective kernels hold during an all-reduce, so an overlapped GEMM does not spill into a second wave. */
 int sa_set_cu_budget(int32_t cus);
 
-/* diagnostics only: per-phase cycle stamps of one wave of sa_attention_bwd when SA_ATTN_DBG=8 (4 workgroups x 8 counters, see attention.hip) */
-int sa_attention_debug_counters(uint64_t* out32);
-/* diagnostics only: cycle stamps of the persistent 256x256 kernel when SA_GEMM_DBG=8 (2 x 8 counters, see gemm_bf16.hip) */
-int sa_gemm_debug_counters(uint64_t* out16);
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
 int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients); accumulate != 0 adds */
@@ -92,7 +88,7 @@ int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const flo
                      int32_t M, int32_t D, void* stream);
 int64_t sa_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
 
-/* ------------------------------------------------------------------ fused attention (head_dim 64, N <= 256)
+/* ------------------------------------------------------------------ fused attention (head_dim 64, N <= 512)
  * Replaces models/mae.py:130-138 (reshape/permute, q k^T * scale, softmax, attn v, transpose/reshape).
  * qkv: bf16 [rows][ld], per row [q(C) | k(C) | v(C)], C = H*64, rows = sequences * N.  out: bf16 [rows][ldo].
  * lse: fp32 [sequences*H][N] log-sum-exp of the scaled scores (saved for backward; may be NULL in fwd).
@@ -226,6 +222,34 @@ int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pr
 /* loss[0] = acc2[0] / acc2[1] again, after acc2 was summed over data-parallel ranks (global masked mean: what one process computes
  * on the global batch, models/mae.py:451-452). */
 int sa_mae_recon_loss_finalize(const float* acc2, float* loss, void* stream);
+
+/* ------------------------------------------------------------------ convolutional stems, channel-last
+ * ConvStem (models/mae.py:46-99: 3x3 conv stride 2 / (2,1), pad 1, no bias -> BatchNorm2d -> ReLU, x4 (x6), then a 1x1 conv) and the
+ * AudioNTT encoder (model.py:130-191: 3x3 conv stride 1 + bias -> BatchNorm2d -> ReLU -> MaxPool2d(2), x2, then an MLP per frame).
+ * A feature map lives as NHWC = row-major [M = B*H*W][C]: it is directly the GEMM / BatchNorm matrix, and the token order of
+ * `x.flatten(2).transpose(1, 2)` (models/mae.py:96).  H_out = (H - 1) / sh + 1 (kernel 3, pad 1), likewise W_out.
+ *   c1_fwd   : first layer (C_in = 1): x fp32 [B][H][W], w fp32 [C_out][9], bias or NULL -> y fp32 [M][C_out]
+ *   c1_wgrad : dw[C_out][9] += dy^T im2col(x), dbias[C_out] += column sums of dy (NULL: skipped); dy bf16 [M][C_out]
+ *   im2col   : x bf16 NHWC -> out bf16 [M][Kpad], column (ky*3 + kx)*C + c, zero padding taps and columns 9C..Kpad-1 (the conv is
+ *              then sa_gemm_bf16 against the weight laid out [C_out][ky][kx][C_in], zero-padded to Kpad)
+ *   col2im   : dP bf16 [M][Kpad] (the GEMM's dgrad) -> dx fp32 NHWC, every element written (gather form, no atomics) */
+int sa_conv3x3_c1_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t sh, int32_t sw, const float* w, const float* bias, int32_t Cout,
+                      float* y, void* stream);
+int sa_conv3x3_c1_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t sh, int32_t sw, const void* dy_bf16, int32_t Cout, float* dw,
+                        float* dbias, void* stream);
+int sa_im2col3x3_bf16(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t sh, int32_t sw, void* out, int32_t Kpad, void* stream);
+int sa_col2im3x3_f32(const void* dP_bf16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t sh, int32_t sw, int32_t Kpad, float* dx, void* stream);
+/* BatchNorm2d statistics of a tall [M][C] map (M = B*H*W in the millions): chunked (mean, M2) partials merged with Chan's formula;
+ * results feed sa_bn_finalize / sa_bn_apply / sa_bn_bwd_apply exactly like sa_bn_colstats / sa_bn_bwd_stats do for the projector.
+ * ws: sa_bn_tall_workspace_bytes(M, C) bytes of scratch. */
+int64_t sa_bn_tall_workspace_bytes(int64_t M, int32_t C);
+int sa_bn_colstats_tall(const float* x, int64_t ld, int64_t M, int32_t C, float* ws, float* mean, float* m2, void* stream);
+int sa_bn_bwd_stats_tall(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ld, int64_t M, int32_t C, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, int32_t relu, float* ws, float* s1, float* s2, void* stream);
+/* MaxPool2d(2, 2) on a bf16 NHWC map (model.py:141,149): y [B][H/2][W/2][C], idx = position of the maximum inside its window (0..3);
+ * backward routes dy (fp32) to that position and writes every element of dx [B][H][W][C] */
+int sa_maxpool2_fwd(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, void* y_bf16, uint8_t* idx, void* stream);
+int sa_maxpool2_bwd(const float* dy, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl_audio_amd import ops
 dev = torch.device("cuda:0")
-S, H, N = 256, 12, 249
+S, H = 256, 12
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 249        # 249: 16 x 16 patches at 10 s; 501: 16 x 8 patches
 C = 64 * H
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(S * N, 3 * C, device=dev, generator=g).to(torch.bfloat16)
@@ -22,12 +23,3 @@ bw = t(lambda: ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv))
 fl = 4.0 * S * H * N * N * 64
 print(f"attention fwd {fw:.1f} us ({fl/fw/1e6:.1f} TFLOP/s)   bwd {bw:.1f} us ({2.5*fl/bw/1e6:.1f} TFLOP/s algorithmic)")
 
-if os.environ.get("SA_ATTN_DBG") == "8":
-    import ctypes
-    from ssl_audio_amd._lib import lib
-    buf = (ctypes.c_uint64 * 32)()
-    assert lib().sa_attention_debug_counters(buf) == 0
-    names = ["stage issue + delta", "stage wait", "pass A", "barrier after A", "restage Q/dO", "pass B", "total"]
-    t00 = min(buf[w * 8 + 7] for w in range(4))
-    for w, wg in enumerate((100, 1100, 2100, 3000)):
-        print(f"attn_bwd wg {wg:4d} (start +{buf[w * 8 + 7] - t00:8d}): " + ", ".join(f"{n} {buf[w * 8 + i]}" for i, n in enumerate(names)))

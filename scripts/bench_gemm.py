@@ -1,38 +1,51 @@
-"""GEMM micro-benchmark at the ViT-B step's shapes (M = 256 sequences x 249 tokens).  Random operands (rule 25)."""
-import sys, os, time
+"""GEMM micro-benchmark at the ViT-B step's shapes AND epilogues (M = 256 sequences x 249 tokens): the 12 launches one transformer
+block's forward + backward makes, exactly as engine.block_forward / block_backward call them.  Random operands (rule 25).
+   python scripts/bench_gemm.py [filter] [reps]          (SA_GEMM_TILE / SA_GEMM_WGRAD_PHASE select kernels, read once per process)"""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl_audio_amd import ops
 dev = torch.device("cuda:0")
-M = 63744
-d = 768
+M, d = 63744, 768
 g = torch.Generator(device=dev).manual_seed(0)
 def rb(*s): return torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
-cases = []
-for name, N, K in [("qkv", 3 * d, d), ("proj", d, d), ("fc1", 4 * d, d), ("fc2", d, 4 * d)]:
-    cases.append((f"fwd  NT {name}", dict(A=rb(M, K), B=rb(N, K), a_kmajor=True, b_kmajor=True, out_bf16=torch.empty(M, N, device=dev, dtype=torch.bfloat16)), 2.0 * M * N * K))
-    cases.append((f"dgrad NN {name}", dict(A=rb(M, N), B=rb(N, K), a_kmajor=True, b_kmajor=False, out_bf16=torch.empty(M, K, device=dev, dtype=torch.bfloat16)), 2.0 * M * N * K))
+def rf(*s): return torch.randn(*s, device=dev, generator=g)
+def e16(*s): return torch.empty(*s, device=dev, dtype=torch.bfloat16)
+x16, h4 = rb(M, d), rb(M, 4 * d)
+q16 = rb(M, 3 * d)
+res = rf(M, d)
+W = {"qkv": rb(3 * d, d) * 0.05, "proj": rb(d, d) * 0.05, "fc1": rb(4 * d, d) * 0.05, "fc2": rb(d, 4 * d) * 0.05}
+bias = {"qkv": rf(3 * d), "proj": rf(d), "fc1": rf(4 * d), "fc2": rf(d)}
+aux = rb(M, 4 * d)
+cases = [
+    ("fwd  NT qkv  bias->bf16", lambda o=e16(M, 3 * d): ops.gemm(x16, W["qkv"], bias=bias["qkv"], out_bf16=o), 2.0 * M * 3 * d * d),
+    ("fwd  NT proj bias+res->f32", lambda o=torch.empty(M, d, device=dev): ops.gemm(x16, W["proj"], bias=bias["proj"], residual=res, out_f32=o), 2.0 * M * d * d),
+    ("fwd  NT fc1  gelu pair", lambda o=e16(M, 4 * d), a=e16(M, 4 * d): ops.gemm(x16, W["fc1"], bias=bias["fc1"], act=3, aux_out=a, out_bf16=o), 2.0 * M * 4 * d * d),
+    ("fwd  NT fc2  bias+res->f32", lambda o=torch.empty(M, d, device=dev): ops.gemm(h4, W["fc2"], bias=bias["fc2"], residual=res, out_f32=o), 2.0 * M * 4 * d * d),
+    ("dgrad NN fc2 *gelu' +colsum", lambda o=e16(M, 4 * d), cs=torch.zeros(4 * d, device=dev): ops.gemm(x16, W["fc2"], b_kmajor=False, act=4, aux_in=aux, out_bf16=o, colsum_out=cs), 2.0 * M * 4 * d * d),
+    ("dgrad NN fc1 ->bf16", lambda o=e16(M, d): ops.gemm(h4, W["fc1"], b_kmajor=False, out_bf16=o), 2.0 * M * 4 * d * d),
+    ("dgrad NN proj ->bf16", lambda o=e16(M, d): ops.gemm(x16, W["proj"], b_kmajor=False, out_bf16=o), 2.0 * M * d * d),
+    ("dgrad NN qkv ->bf16", lambda o=e16(M, d): ops.gemm(q16, W["qkv"], b_kmajor=False, out_bf16=o), 2.0 * M * 3 * d * d),
+]
+for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16), ("fc1", 4 * d, d, h4, x16), ("fc2", d, 4 * d, x16, h4)]:
     out = torch.zeros(N, K, device=dev)
-    cases.append((f"wgrad TN {name}", dict(A=rb(M, N), B=rb(M, K), a_kmajor=False, b_kmajor=False, out_f32=out, split_k=ops.pick_split_k(N, K, M)), 2.0 * M * N * K))
-    cases.append((f"wgrad256 {name}", dict(A=cases[-1][1]["A"], B=cases[-1][1]["B"], a_kmajor=False, b_kmajor=False, out_f32=out,
-                                          split_k=ops.pick_split_k(N, K, M, tile=256), tile256=True), 2.0 * M * N * K))
-def run(kw):
-    kw = dict(kw); A = kw.pop("A"); B = kw.pop("B")
-    ops.gemm(A, B, **kw)
+    use256 = ((N + 255) // 256) * ((K + 255) // 256) >= 16
+    sk = ops.pick_split_k(N, K, M, tile=256) if use256 else ops.pick_split_k(N, K, M)
+    cases.append((f"wgrad TN {name} split{sk}{' 256' if use256 else ''}",
+                  lambda out=out, dy=dy, xx=xx, sk=sk, use256=use256: ops.gemm(dy, xx, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=sk, tile256=use256), 2.0 * M * N * K))
 only = sys.argv[1] if len(sys.argv) > 1 else None
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tot_t = tot_f = 0.0
-for name, kw, fl in cases:
+for name, fn, fl in cases:
     if only and only not in name:
         continue
-    for _ in range(3): run(kw)
+    for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = reps
-    for _ in range(n): run(kw)
+    for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    ms = e0.elapsed_time(e1) / reps
     tot_t += ms; tot_f += fl
-    print(f"{name:18s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s" + (f"  split_k={kw.get('split_k')}" if 'split_k' in kw else ""))
-print(f"ALL (one layer fwd+bwd GEMMs): {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
+    print(f"{name:30s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
+print(f"ALL (one block's fwd+bwd GEMMs, tile={os.environ.get('SA_GEMM_TILE', 'default')}): {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")

@@ -41,10 +41,8 @@ _SIGNATURES = {
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
     "sa_layernorm_bwd_workspace_bytes": [I32, I32],
-    "sa_gemm_debug_counters": [P],
     "sa_set_cu_budget": [I32],
     "sa_lars_step": [P, P, P, I64, F32, F32, F32, F32, I32, P, P, P],
-    "sa_attention_debug_counters": [P],
     "sa_gemm_colsum_workspace_bytes": [I32, I32],
     "sa_mix_gaussian_noise": [P, P, I64, F32, F32, P, P],
     "sa_running_norm": [P, I32, I64, P, I32, I32, F32, P, P],
@@ -56,6 +54,15 @@ _SIGNATURES = {
     "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, P, P, P],
     "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P],
     "sa_mae_recon_loss_finalize": [P, P, P],
+    "sa_conv3x3_c1_fwd": [P, I32, I32, I32, I32, I32, P, P, I32, P, P],
+    "sa_conv3x3_c1_wgrad": [P, I32, I32, I32, I32, I32, P, I32, P, P, P],
+    "sa_im2col3x3_bf16": [P, I32, I32, I32, I32, I32, I32, P, I32, P],
+    "sa_col2im3x3_f32": [P, I32, I32, I32, I32, I32, I32, I32, P, P],
+    "sa_bn_tall_workspace_bytes": [I64, I32],
+    "sa_bn_colstats_tall": [P, I64, I64, I32, P, P, P, P],
+    "sa_bn_bwd_stats_tall": [P, I32, I64, P, I64, I64, I32, P, P, P, P, I32, P, P, P, P],
+    "sa_maxpool2_fwd": [P, I32, I32, I32, I32, P, P, P],
+    "sa_maxpool2_bwd": [P, P, I32, I32, I32, I32, P, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -1,4 +1,4 @@
-// Fused multi-head self-attention forward / backward for the ViT encoder (head_dim 64, N <= 256 tokens).
+// Fused multi-head self-attention forward / backward for the ViT encoder (head_dim 64, N <= 512 tokens).
 // Replaces models/mae.py:133-138: softmax(q k^T * hd^-0.5) v, reading q/k/v straight out of the packed
 // [rows, 3*C] qkv activation (no permute copies) and writing [rows, C] in the layout `proj` consumes.
 //
@@ -10,6 +10,9 @@
 // through ds_read_b64_tr_b16, so no transposed copy exists anywhere.
 // Backward recomputes P from the saved log-sum-exp: pass A (wave owns query tiles) produces dQ, pass B
 // (wave owns key tiles) produces dK and dV, so no gradient is ever summed across waves or workgroups.
+// Two instantiations: NMAX = 256 (the 16 x 16-patch ViTs at 10 s: 249 tokens; 64 KiB of LDS, two workgroups per CU) and
+// NMAX = 512 (the 16 x 8-patch ConvStem ViTs at 10 s: 501 tokens; the head's K and V are 128 KiB, one workgroup per CU, and the
+// exact softmax keeps 512 scores per query in 128 registers).
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
@@ -17,8 +20,7 @@
 namespace {
 
 constexpr int HD = 64;          // head dim
-constexpr int NMAX = 256;       // max tokens per sequence
-constexpr int IMG = NMAX * HD * 2;  // bytes of one [256][64] bf16 LDS image
+constexpr int NMAX_ALL = 512;   // max tokens per sequence over all instantiations
 constexpr int NW_FWD = 8;           // waves per workgroup, forward (64 KiB of LDS -> two workgroups = 16 waves per CU)
 constexpr int NW_BWD = 8;           // backward: 8 waves per workgroup, two workgroups per CU (66 KiB of LDS each)
 
@@ -73,9 +75,12 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 #define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
 
 // =====================================================================================================
-__global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+template <int NMAX>
+__global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = NMAX * HD * 2;      // bytes of one [NMAX][64] bf16 LDS image
+  constexpr int NKT = NMAX / 16, NKS = NMAX / 32;
   char* Kimg = smem;
   char* Vimg = smem + IMG;
   const int lane = threadIdx.x & 63;
@@ -109,12 +114,12 @@ __global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* 
       qf[ks] = __builtin_bit_cast(bf16x8, raw);
     }
     // S^T tiles: st[kt][r] = score(key = 16*kt + 4*g + r, query)
-    f32x4 st[16];
+    f32x4 st[NKT];
     float mx = -INFINITY;
     f32x4 kb = kbias;                                  // opaque copy: keeps the 16 per-tile selects below from being hoisted
     asm volatile("" : "+v"(kb));                       // out of the query-tile loop (64 live VGPRs -> spills)
 #pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {
         if (kt == nkt - 1) st[kt] = kb;                // padding keys start at -inf: the MFMA accumulate keeps them there
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* 
     const float c2 = scale * 1.44269504088896340736f;            // exp(scale * (s - max)) = exp2(c2 * s - c2 * max): one fma + v_exp
     const float mb = mx * c2;
 #pragma unroll
-    for (int kt = 0; kt < 16; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
+    for (int ps = 0; ps < NKS; ++ps) {
       if (ps < nks) {
         const bf16x8 pf = pack8(st[2 * ps], st[2 * ps + 1]);
 #pragma unroll
@@ -168,17 +173,14 @@ __global__ __launch_bounds__(64 * NW_FWD, 4) void attn_fwd_kernel(const bf16_t* 
 }
 
 // =====================================================================================================
-__device__ unsigned long long sa_attn_prof[4][8];   // DBG & 8: cycle stamps of wave 3 of workgroups 100 / 1100 / 2100 / 3000: staging, pass A, restaging, pass B, total
-#define SA_ASTAMP() ((DBG & 8) ? __builtin_readcyclecounter() : 0ull)
-
-// DBG (SA_ATTN_DBG, timing experiments only, results wrong): 1 = one transposing read per 4 d-tiles, 2 = one row read per 2 k-steps, 4 = no exp
-template <int DBG = 0>
-__global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
+template <int NMAX>
+__global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Two 32 KiB images at a time (66 KiB with the statistics -> two workgroups per CU): K,V during pass A, then the same
-  // LDS is re-staged with Q,dO for pass B.  The operand that is NOT in LDS is read as 16-byte row fragments from global.
+  // Two images at a time (NMAX = 256: 2 x 32 KiB, 66 KiB with the statistics -> two workgroups per CU): K,V during pass A, then the
+  // same LDS is re-staged with Q,dO for pass B.  The operand that is NOT in LDS is read as 16-byte row fragments from global.
+  constexpr int IMG = NMAX * HD * 2;
   char* Kimg = smem;
   char* Vimg = smem + IMG;
   char* Qimg = smem;                                 // pass B reuses the two images
@@ -195,7 +197,6 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
   const int nkt = (N + 15) >> 4;
   const int nks = (N + 31) >> 5;
   const int nrows = nks * 32;
-  const unsigned long long t0 = SA_ASTAMP();
   stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
   // delta[q] = sum_d dO[q][d] * O[q][d], lse -> LDS.  Eight lanes share a query row (8 x 16 B = the row's 128 bytes of one head), so
@@ -229,10 +230,8 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
       }
     }
   }
-  const unsigned long long t0b = SA_ASTAMP();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const unsigned long long t1 = SA_ASTAMP();
 
   const int g = lane >> 4, c = lane & 15;
   // per-lane LDS offsets, loop invariant: tile bases are multiples of 16 rows, so (row & 7) never depends on the tile
@@ -243,9 +242,9 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) trf[dt] = rr0 * 128 + ((((dt * 2) + (pp >> 1)) ^ (rr0 & 7)) << 4) + (pp & 1) * 8;
   }
-  auto RF = [&](const char* img, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(img + tile * 2048 + ((ks && !(DBG & 2)) ? rf1 : rf0)); };
+  auto RF = [&](const char* img, int tile, int ks) { return *reinterpret_cast<const bf16x8*>(img + tile * 2048 + (ks ? rf1 : rf0)); };
   auto TR = [&](const char* img, int step, int dt) {
-    const char* b = img + step * 4096 + trf[(DBG & 1) ? 0 : dt];
+    const char* b = img + step * 4096 + trf[dt];
     s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
     s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 2048));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
         dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = ((DBG & 4) ? fmaf(sv[r], c2, -lq) : __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq)));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
+          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
           ds[u][r] = p * (dp[r] - dq_delta);                              // the softmax scale is applied once, to the accumulator
         }
       }
@@ -309,14 +308,11 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
   }
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
-  const unsigned long long t2 = SA_ASTAMP();
   __syncthreads();                                   // every wave is done reading the K / V images
-  const unsigned long long t2b = SA_ASTAMP();
   stage_rows(rs, Qimg, ld, h * HD, nqs * 32, wave, lane, NW_BWD);
   stage_rows(rd, Dimg, ldo, h * HD, nqs * 32, wave, lane, NW_BWD);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const unsigned long long t3 = SA_ASTAMP();
   for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
@@ -342,7 +338,7 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
         const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = ((DBG & 4) ? fmaf(sv[r], c2, -lq4[r]) : __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r])));
+          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r]));
           pp[u][r] = p;
           ds[u][r] = p * (dp[r] - dq4[r]);
         }
@@ -366,41 +362,17 @@ __global__ __launch_bounds__(64 * NW_BWD, 4) void attn_bwd_kernel(const bf16_t* 
       }
     }
   }
-  if constexpr (DBG & 8) {
-    const int which = blockIdx.x == 100 ? 0 : blockIdx.x == 1100 ? 1 : blockIdx.x == 2100 ? 2 : blockIdx.x == 3000 ? 3 : -1;
-    if (which >= 0 && threadIdx.x == 64 * 3) {
-      const unsigned long long t4 = SA_ASTAMP();
-      unsigned long long* sa_attn_prof_w = sa_attn_prof[which];
-      sa_attn_prof_w[0] = t0b - t0;   // issue of the K/V staging + delta / lse prologue
-      sa_attn_prof_w[1] = t1 - t0b;   // wait for it
-      sa_attn_prof_w[2] = t2 - t1;    // pass A (this wave)
-      sa_attn_prof_w[3] = t2b - t2;   // barrier after pass A (slowest wave)
-      sa_attn_prof_w[4] = t3 - t2b;   // Q / dO restaging
-      sa_attn_prof_w[5] = t4 - t3;    // pass B (this wave)
-      sa_attn_prof_w[6] = t4 - t0;    // total
-      sa_attn_prof_w[7] = t0;         // start stamp
-    }
-  }
 }
 
 }  // namespace
 
-extern "C" int sa_attention_debug_counters(uint64_t* out8 /* 4 x 8 */) {
-  if (hipDeviceSynchronize() != hipSuccess ||
-      hipMemcpyFromSymbol(out8, HIP_SYMBOL(sa_attn_prof), 32 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost) != hipSuccess) {
-    sa_set_error("sa_attention_debug_counters: copy failed");
-    return 2;
-  }
-  return 0;
-}
-
 static int attn_check(const char* who, const void* qkv, int64_t rows, int64_t ld, int C, int H, int N) {
   SA_CHECK_ARG(qkv && rows > 0, "%s: null/empty input", who);
   SA_CHECK_ARG(H > 0 && C == H * HD, "%s: head_dim must be %d (C=%d, H=%d)", who, HD, C, H);
-  SA_CHECK_ARG(N > 0 && N <= NMAX, "%s: sequence length %d outside [1, %d]", who, N, NMAX);
+  SA_CHECK_ARG(N > 0 && N <= NMAX_ALL, "%s: sequence length %d outside [1, %d]", who, N, NMAX_ALL);
   SA_CHECK_ARG(rows % N == 0, "%s: rows=%lld not a multiple of N=%d", who, (long long)rows, N);
   SA_CHECK_ARG(ld >= 3 * C && ld % 8 == 0 && ((uintptr_t)qkv & 15) == 0, "%s: qkv must have 16-byte aligned rows", who);
-  SA_CHECK_ARG((rows + NMAX) * ld * 2 < ((int64_t)1 << 32), "%s: qkv larger than the 4 GiB buffer-descriptor range", who);
+  SA_CHECK_ARG((rows + NMAX_ALL) * ld * 2 < ((int64_t)1 << 32), "%s: qkv larger than the 4 GiB buffer-descriptor range", who);
   return 0;
 }
 
@@ -409,14 +381,27 @@ extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32
   if (n_query <= 0 || n_query > N) n_query = N;
   if (attn_check("sa_attention_fwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && ldo >= C && ldo % 4 == 0, "sa_attention_fwd: bad output");
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
-    configured = true;
-  }
   const int S = (int)(rows / N);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(S * H), dim3(64 * NW_FWD), 2 * IMG, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
-                     scale, (bf16_t*)out, (int)ldo, lse);
+  if (N <= 256) {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HD * 2);
+      configured = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(S * H), dim3(64 * NW_FWD), 2 * 256 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H,
+                       N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+  } else {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 2) != hipSuccess) {
+        sa_set_error("sa_attention_fwd: 128 KiB of LDS per workgroup refused");
+        return 2;
+      }
+      configured = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<512>, dim3(S * H), dim3(64 * NW_FWD), 2 * 512 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H,
+                       N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+  }
   SA_LAUNCH_CHECK("sa_attention_fwd");
   return 0;
 }
@@ -427,29 +412,29 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
   if (attn_check("sa_attention_bwd", qkv, rows, ld, C, H, N)) return 1;
   SA_CHECK_ARG(out && dout && lse && dqkv && ldo >= C && ldo % 8 == 0, "sa_attention_bwd: bad args");
   SA_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)out & 15) == 0, "sa_attention_bwd: out/dout must be 16-byte aligned");
-  static const char* pad = getenv("SA_ATTN_LDS_PAD");          // experiment: extra LDS bytes per workgroup (occupancy probe)
-  const int lds = 2 * IMG + 2 * NMAX * (int)sizeof(float) + (pad ? atoi(pad) : 0);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    configured = true;
-  }
   const int S = (int)(rows / N);
-  static const char* dbg = getenv("SA_ATTN_DBG");
-  if (dbg && atoi(dbg) > 0) {
-#define SA_ATTN_CASE(D)                                                                                                                      \
-  case D:                                                                                                                                    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);           \
-    hipLaunchKernelGGL(attn_bwd_kernel<D>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, \
-                       N, n_query, scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);                             \
-    break;
-    switch (atoi(dbg)) { SA_ATTN_CASE(1) SA_ATTN_CASE(2) SA_ATTN_CASE(3) SA_ATTN_CASE(4) SA_ATTN_CASE(7) SA_ATTN_CASE(8) default: break; }
-#undef SA_ATTN_CASE
-    SA_LAUNCH_CHECK("sa_attention_bwd(dbg)");
-    return 0;
+  if (N <= 256) {
+    constexpr int lds = 2 * 256 * HD * 2 + 2 * 256 * (int)sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      configured = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+                       scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
+  } else {
+    constexpr int lds = 2 * 512 * HD * 2 + 2 * 512 * (int)sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        sa_set_error("sa_attention_bwd: 132 KiB of LDS per workgroup refused");
+        return 2;
+      }
+      configured = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel<512>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+                       scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   }
-  hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query, scale,
-                     (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   SA_LAUNCH_CHECK("sa_attention_bwd");
   return 0;
 }

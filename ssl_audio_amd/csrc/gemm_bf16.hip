@@ -329,266 +329,12 @@ int launch256(GemmParams p, hipStream_t stream) {
 }
 
 // =====================================================================================================
-// 256 x 128 x 64 tile, THREE LDS stages (3 x 48 KiB), 512 threads = 8 waves (4 x 2, each 64 x 64).
-// The K-tile two steps ahead is requested at the top of every iteration and only the one needed NEXT is awaited
-// (`s_waitcnt vmcnt(6)`: this wave's 6 newest LDS-DMA requests stay in flight across the raw s_barrier), so operand
-// delivery from L2 has two full iterations of MFMA work to hide behind instead of being a burst-then-wait.
-// Requests past the last K-tile are sent out of range (zero fill, no memory traffic) so the count stays exact.
-template <bool KMAJOR>
-__device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
-                                            int wave, int lane, bool valid) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = wave * 2 + i;
-    uint32_t voff;
-    if constexpr (KMAJOR) {
-      const int row = q * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ (row & 7);
-      voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
-    } else {
-      const int krow = q * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ ks_swz(krow);
-      voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
-    }
-    voff = valid ? voff : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
-  }
-}
-
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A half0 | A half1 | B]
-  constexpr int STAGE = 3 * TILE_BYTES;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;      // wave rows wr*64.., cols wc*64..
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int GM = p.gm256;
-  const int group_sz = GM * p.tiles_n;
-  const int grp = lid / group_sz, within = lid - grp * group_sz;
-  const int gm = min(GM, p.tiles_m - grp * GM);
-  const int tm = grp * GM + within % gm, tn = within / gm;
-  const int m0 = tm * 256, n0 = tn * 128;
-
-  const int ksteps = (p.K + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int slot, int kt) {
-    char* buf = smem + slot * STAGE;
-    const bool valid = kt < ksteps;
-    stage_tile8<A_KM>(ra, buf, p.lda, m0, kt * BK, wave, lane, valid);
-    stage_tile8<A_KM>(ra, buf + TILE_BYTES, p.lda, m0 + 128, kt * BK, wave, lane, valid);
-    stage_tile8<B_KM>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, kt * BK, wave, lane, valid);
-  };
-
-  stage(0, 0);
-  stage(1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int slot = 0;
-  for (int kt = 0; kt < ksteps; ++kt) {
-    int nslot = slot + 2;
-    if (nslot >= 3) nslot -= 3;
-    stage(nslot, kt + 2);
-    const char* ta = smem + slot * STAGE + (wr >> 1) * TILE_BYTES;
-    const char* tb = smem + slot * STAGE + 2 * TILE_BYTES;
-    const int arow = (wr & 1) * 64, bcol = wc * 64;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KM>(ta, arow + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    // own LDS reads retired (the slot just read is re-staged right after the barrier) + next K-tile's DMA landed
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    slot = slot + 1 == 3 ? 0 : slot + 1;
-  }
-
-  // ---------------------------------------------------------------- epilogue
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the out-of-range tail requests still zero-fill LDS: let them land
-  __builtin_amdgcn_s_barrier();
-  wave_epilogue_64x64(p, acc, m0 + wr * 64, n0 + wc * 64, smem + wave * EPI_BYTES, lane);
-}
-
-template <bool A_KM, bool B_KM>
-int launch_p3(GemmParams p, hipStream_t stream) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 127) / 128;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p3_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              9 * TILE_BYTES);
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm_p3_kernel<A_KM, B_KM>), dim3(p.tiles_m * p.tiles_n), dim3(512), 9 * TILE_BYTES, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(p3)");
-  return 0;
-}
-
-
-// =====================================================================================================
-// Persistent 128 x 128 x 64 kernel (forward / dgrad, no split-K): a workgroup walks tiles lid, lid + grid, ...  The first
-// K-tile of the NEXT output tile is requested during the last K-iteration of the current one and lands while the epilogue
-// runs (which stages through the pipeline stage that was just consumed), so neither the pipeline fill nor the store tail
-// of a 12-iteration (K = 768) tile is exposed any more.
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_persist_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A tile | B tile]
-  constexpr int STAGE = 2 * TILE_BYTES;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  constexpr int GM = 8;
-  const int group_sz = GM * p.tiles_n;
-  auto coords = [&](int t, int& m0, int& n0) {
-    const int grp = t / group_sz, within = t - grp * group_sz;
-    const int gm = min(GM, p.tiles_m - grp * GM);
-    m0 = (grp * GM + within % gm) * BM;
-    n0 = (within / gm) * BN;
-  };
-  const int ksteps = p.K / BK + ((p.K % BK) ? 1 : 0);
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-
-  int t = lid;
-  if (t >= ntiles) return;
-  int m0, n0;
-  coords(t, m0, n0);
-  stage_tile<A_KM>(ra, smem, p.lda, m0, 0, wave, lane);
-  stage_tile<B_KM>(rb, smem + TILE_BYTES, p.ldb, n0, 0, wave, lane);
-  int cur = 0;
-  while (true) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first K-tile of this output tile (and the previous epilogue's stores)
-    __builtin_amdgcn_s_barrier();
-    const int tnext = t + nwg;
-    const bool has_next = tnext < ntiles;
-    int m0n = 0, n0n = 0;
-    if (has_next) coords(tnext, m0n, n0n);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < ksteps; ++kt) {
-      char* nxt = smem + (cur ^ 1) * STAGE;
-      const bool more = kt + 1 < ksteps;
-      if (more) {
-        stage_tile<A_KM>(ra, nxt, p.lda, m0, (kt + 1) * BK, wave, lane);
-        stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0, (kt + 1) * BK, wave, lane);
-      } else if (has_next) {
-        stage_tile<A_KM>(ra, nxt, p.lda, m0n, 0, wave, lane);
-        stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0n, 0, wave, lane);
-      }
-      const char* ta = smem + cur * STAGE;
-      const char* tb = ta + TILE_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_KM>(ta, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_KM>(tb, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      }
-      if (more) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
-      }
-    }
-    // every wave has consumed stage `cur` (its MFMAs needed the fragments): it becomes the epilogue's staging area while
-    // stage cur^1 is receiving the next tile.  Raw barrier: the pending LDS-DMA must NOT be drained here.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    wave_epilogue_64x64<true>(p, acc, m0 + wr * 64, n0 + wc * 64, smem + cur * STAGE + wave * 8192, lane);
-    if (!has_next) break;
-    t = tnext; m0 = m0n; n0 = n0n;
-    cur ^= 1;
-  }
-}
-
-template <bool A_KM, bool B_KM>
-int launch_persist(GemmParams p, hipStream_t stream) {
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      sa_set_error("sa_gemm_bf16: cannot query the device");
-      return 2;
-    }
-    slots = 2 * prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              4 * TILE_BYTES);
-  }
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              4 * TILE_BYTES);
-    configured = true;
-  }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int use = budget_slots(slots / 2, 2);
-  const int grid = ntiles < use ? ntiles : use;
-  hipLaunchKernelGGL((gemm_persist_kernel<A_KM, B_KM>), dim3(grid), dim3(NTHREADS), 4 * TILE_BYTES, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(persistent)");
-  return 0;
-}
-
-// =====================================================================================================
 // Persistent 256 x 256 x 64 kernel (forward / dgrad): one workgroup per CU walks tiles lid, lid + grid, ...  With a single
 // resident workgroup nothing else hides the pipeline fill and the store tail of a 12-iteration (K = 768) tile, so the
 // kernel hides them itself: the next tile's first K-tile is requested during the last K-iteration and lands while the
 // epilogue runs, and the epilogue stages through the 64 KiB pipeline stage that was just consumed (8 KiB per wave, two
 // 64-row passes).
-// cycle stamps of one wave (DBG bit 3, SA_GEMM_DBG=8): [0] K-steps seen, [1] fragment+MFMA section, [2] vmcnt wait, [3] barrier wait,
-// [4] epilogue, [5] total, [6] tile-top wait.  Read back with sa_gemm_debug_counters().
-__device__ unsigned long long sa_gemm_prof[2][8];
-#define SA_STAMP() ((DBG & 8) ? __builtin_readcyclecounter() : 0ull)
-
-// experiment knob for the persistent kernel (SA_GEMM_DBG): bit 0 = LDS-DMA only on the first K-step, bit 1 = fragment reads
-// only on the first K-step, bit 2 = no MFMA (operands kept alive).  Results are wrong by design; timing isolates a pipe.
-template <int DBG>
-__device__ __forceinline__ f32x4 mfma_dbg(const bf16x8& x, const bf16x8& y, const f32x4& c) {
-  if constexpr (DBG & 4) {
-    asm volatile("" ::"v"(x), "v"(y));
-    return c;
-  } else {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
-  }
-}
-
-template <bool A_KM, bool B_KM, int DBG = 0, int EPI = 0>
+template <bool A_KM, bool B_KM, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
   constexpr int BUF = 4 * TILE_BYTES;
@@ -625,13 +371,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   coords(t, m0, n0);
   stage_all(smem, m0, n0, 0);
   int cur = 0;
-  unsigned long long pc_mfma = 0, pc_vm = 0, pc_bar = 0, pc_epi = 0, pc_top = 0, pc_steps = 0, pc_ebar = 0;
-  const unsigned long long pc_begin = SA_STAMP();
   while (true) {
-    const unsigned long long tt0 = SA_STAMP();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    pc_top += SA_STAMP() - tt0;
     const int tnext = t + nwg;
     const bool has_next = tnext < ntiles;
     int m0n = 0, n0n = 0;
@@ -649,38 +391,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
       // the second wave row requests its share of the next K-tile mid-step instead of at the top: halves the burst that blocks
       // every wave on the memory pipe's issue queue right after the barrier (measured 2-4 % on the forward shapes)
       const bool late = p.stagger && wr == 1;
-      if ((!(DBG & 1) || kt == 0) && !late) {
+      if (!late) {
         if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
         else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
       }
       const char* ta = smem + cur * BUF + wr * TILE_BYTES;
       const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
       const int bcol = (wc & 1) * 64;
-      const unsigned long long s0 = SA_STAMP();
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[i][j]);
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2) || kt == 0) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[i][2 + j]);
+          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
       if (late) {
         if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
         else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
@@ -688,62 +429,43 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) if (!(DBG & 2)) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma_dbg<DBG>(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j]);
+          for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma_dbg<DBG>(fb0[j][ks], fa[i][ks], acc[4 + i][j]);
-      if constexpr (DBG & 8) {
-        asm volatile("s_nop 0" ::"v"(acc[4][0]), "v"(acc[7][1]));   // the last MFMA results exist: the section really ended
-        const unsigned long long s1 = SA_STAMP();
-        pc_mfma += s1 - s0;
-        ++pc_steps;
-        if (more) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const unsigned long long s2 = SA_STAMP();
-          __builtin_amdgcn_s_barrier();
-          const unsigned long long s3 = SA_STAMP();
-          pc_vm += s2 - s1;
-          pc_bar += s3 - s2;
-          cur ^= 1;
-        }
-      } else if (more) {
+          for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
+      if (more) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
       }
     }
-    const unsigned long long e0 = SA_STAMP();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // raw: the next tile's LDS-DMA stays in flight
-    pc_ebar += SA_STAMP() - e0;
     char* wl = smem + cur * BUF + wave * 8192;
     if constexpr (EPI != 0) {
-      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
-      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
+      float4 bias4[4];
+      const bool has_bias = p.bias != nullptr && n0 + wc * 64 < p.N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bias4[j] = has_bias ? *reinterpret_cast<const float4*>(p.bias + n0 + wc * 64 + j * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane, nullptr, bias4);
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane, nullptr, bias4);
     } else {
       wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
       wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
     }
-    pc_epi += SA_STAMP() - e0;
     if (!has_next) break;
     t = tnext; m0 = m0n; n0 = n0n;
     cur ^= 1;
-  }
-  if constexpr (DBG & 8) {
-    const int which = blockIdx.x == 0 ? 0 : (blockIdx.x == 133 ? 1 : -1);
-    if (which >= 0 && threadIdx.x == 64 * 5) {          // wave 5 of two workgroups
-      unsigned long long* o = sa_gemm_prof[which];
-      o[0] = pc_steps; o[1] = pc_mfma; o[2] = pc_vm; o[3] = pc_bar; o[4] = pc_epi; o[5] = SA_STAMP() - pc_begin; o[6] = pc_top; o[7] = pc_ebar;
-    }
   }
 }
 
@@ -764,33 +486,17 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
                               8 * TILE_BYTES);
   }
   const int ntiles = p.tiles_m * p.tiles_n;
-  if constexpr (A_KM && B_KM) {
-    static const char* dbg = getenv("SA_GEMM_DBG");
-    if (dbg && atoi(dbg) > 0) {
-      const dim3 g(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), b(512);
-#define SA_DBG_CASE(D)                                                                                                     \
-  case D:                                                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, D>),                        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                                 \
-    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, D>), g, b, 8 * TILE_BYTES, stream, p);                           \
-    break;
-      switch (atoi(dbg)) { SA_DBG_CASE(1) SA_DBG_CASE(2) SA_DBG_CASE(3) SA_DBG_CASE(4) SA_DBG_CASE(5) SA_DBG_CASE(6) SA_DBG_CASE(7) SA_DBG_CASE(8) }
-#undef SA_DBG_CASE
-      SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, dbg)");
-      return 0;
-    }
-  }
   const dim3 grid(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots));
   if constexpr (A_KM && B_KM) {            // the forward layout gets kernels specialised on the compact epilogues 1..3
 #define SA_EPI_CASE(E)                                                                                                     \
   case E: {                                                                                                                \
     static bool cfg = false;                                                                                               \
     if (!cfg) {                                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, 0, E>),                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, E>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                               \
       cfg = true;                                                                                                          \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, 0, E>), grid, dim3(512), 8 * TILE_BYTES, stream, p);             \
+    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, E>), grid, dim3(512), 8 * TILE_BYTES, stream, p);             \
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
     return 0;                                                                                                              \
   }
@@ -799,182 +505,6 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
   }
   hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), 8 * TILE_BYTES, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
-  return 0;
-}
-
-
-// =====================================================================================================
-// Persistent 256 x 256 x 64 kernel, software-pipelined across the K-step barrier ("mode 7").
-// The lock-step kernel above starts every K-step with all 8 waves issuing 12 KiB of fragment reads at once and the MFMA
-// pipe idle until they drain.  Here the K-step barrier sits three quarters of the way through the step: quadrants
-// Q0..Q2 run, then (vmcnt(0) + barrier) proves the NEXT stage has landed and THIS stage is no longer read, the LDS-DMA
-// for K-tile g+2 is requested into this stage, the first fragments of K-tile g+1 are read, and only then does Q3 (whose
-// operands are already in registers) issue -- so the fragment reads that open a K-step always overlap 16 MFMAs.  The
-// quadrant order mirrors on odd steps (B-low / B-high swap roles) so the prefetch always targets registers that are dead.
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A half0 | A half1 | B half0 | B half1]
-  constexpr int BUF = 4 * TILE_BYTES;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int GM = p.gm256;
-  const int group_sz = GM * p.tiles_n;
-  auto coords = [&](int t, int& m0, int& n0) {
-    const int grp = t / group_sz, within = t - grp * group_sz;
-    const int gm = min(GM, p.tiles_m - grp * GM);
-    m0 = (grp * GM + within % gm) * 256;
-    n0 = (within / gm) * 256;
-  };
-  const int ksteps = (p.K + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-
-  int t = lid;
-  if (t >= ntiles) return;
-  int m0, n0;
-  coords(t, m0, n0);
-
-  // request cursor: the next K-tile (tile rt at rm0/rn0, K-step rk) to bring in; runs ahead of the compute by 2 K-tiles
-  int rt = t, rm0 = m0, rn0 = n0, rk = 0;
-  auto request = [&](char* buf) {
-    if (rt >= ntiles) return;
-    stage_tile<A_KM, 8>(ra, buf, p.lda, rm0, rk * BK, wave, lane);
-    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, rm0 + 128, rk * BK, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, rn0, rk * BK, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, rn0 + 128, rk * BK, wave, lane);
-    if (++rk == ksteps) {
-      rk = 0;
-      rt += nwg;
-      if (rt < ntiles) coords(rt, rm0, rn0);
-    }
-  };
-
-  request(smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  request(smem + BUF);
-  int cur = 0;
-  const int bcol = (wc & 1) * 64;
-
-  while (true) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 fal[4][2], fah[4][2], fb[2][2][2];   // A rows 0..63 / 64..127 of the wave tile; B columns [half][j][ks]
-    {
-      const char* ta = smem + cur * BUF + wr * TILE_BYTES;
-      const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fal[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb[0][j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
-    }
-
-    auto step = [&](auto parity, bool last) {
-      constexpr int P = decltype(parity)::value, O = 1 - P;
-      const char* ta = smem + cur * BUF + wr * TILE_BYTES;
-      const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb[O][j][ks] = load_frag<B_KM>(tb, bcol + O * 32 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fah[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][2 * P + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j][ks], fal[i][ks], acc[i][2 * P + j], 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][2 * O + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[O][j][ks], fal[i][ks], acc[i][2 * O + j], 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][2 * O + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[O][j][ks], fah[i][ks], acc[4 + i][2 * O + j], 0, 0, 0);
-      // ---- the K-step barrier: next stage landed, this stage dead
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (!last) {
-        request(smem + cur * BUF);
-        const char* na = smem + (cur ^ 1) * BUF + wr * TILE_BYTES;
-        const char* nb = smem + (cur ^ 1) * BUF + (2 + (wc >> 1)) * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fal[i][ks] = load_frag<A_KM>(na, i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fb[O][j][ks] = load_frag<B_KM>(nb, bcol + O * 32 + j * 16, ks, lane);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[4 + i][2 * P + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j][ks], fah[i][ks], acc[4 + i][2 * P + j], 0, 0, 0);
-      cur ^= 1;
-    };
-
-    for (int kt = 0; kt < ksteps; kt += 2) {
-      step(std::integral_constant<int, 0>{}, kt + 1 == ksteps);
-      if (kt + 1 < ksteps) step(std::integral_constant<int, 1>{}, kt + 2 == ksteps);
-    }
-    // epilogue: stage through the K-stage consumed last (every wave is past its barrier, so nobody reads it any more)
-    char* wl = smem + (cur ^ 1) * BUF + wave * 8192;
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
-    t += nwg;
-    if (t >= ntiles) break;
-    coords(t, m0, n0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // all epilogue scratch reads done: the stage may be refilled
-    request(smem + (cur ^ 1) * BUF);
-  }
-}
-
-template <bool A_KM, bool B_KM>
-int launch256_pp(GemmParams p, hipStream_t stream) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      sa_set_error("sa_gemm_bf16: cannot query the device");
-      return 2;
-    }
-    slots = prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pp_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              8 * TILE_BYTES);
-  }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm256_pp_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(256 pipelined)");
   return 0;
 }
 
@@ -1258,181 +788,6 @@ int launch256_ring(GemmParams p, hipStream_t stream) {
 }
 
 
-// =====================================================================================================
-// Persistent 256 x 256 x 64 kernel with EARLY operand requests ("mode 9").
-// Finding: the K-loop runs at the round-trip time of one 64 KiB LDS-DMA stage (~2900 cycles), not at the MFMA
-// floor (2048), because with two LDS buffers a stage can only be requested when the step that reads its buffer has ended.
-// But a step's LAST LDS read (the second half of the A fragments) happens before quadrants Q2/Q3 issue: a second barrier
-// there proves the buffer dead half a step early, so the request for the K-tile after next goes out then -- 1.5 steps of
-// lead and up to two stages in flight, with no extra LDS or registers.  The eight requests are trickled between the
-// MFMAs of Q2/Q3; the end-of-step wait is vmcnt(8) (those eight stay in flight; older stores cannot fool the count because
-// loads retire in order).  On a tile's last step the request is deferred past the epilogue, which borrows that buffer.
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(512, 2) void gemm256_early_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A half0 | A half1 | B half0 | B half1]
-  constexpr int BUF = 4 * TILE_BYTES;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int GM = p.gm256;
-  const int group_sz = GM * p.tiles_n;
-  auto coords = [&](int t, int& m0, int& n0) {
-    const int grp = t / group_sz, within = t - grp * group_sz;
-    const int gm = min(GM, p.tiles_m - grp * GM);
-    m0 = (grp * GM + within % gm) * 256;
-    n0 = (within / gm) * 256;
-  };
-  const int ksteps = (p.K + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
-
-  int t = lid;
-  if (t >= ntiles) return;
-  int m0, n0;
-  coords(t, m0, n0);
-
-  struct StageReq { int m0, n0, k0, valid; };
-  int rt = t, rm0 = m0, rn0 = n0, rk = 0;              // request cursor over this workgroup's K-tile stream
-  auto next_stage = [&]() {
-    StageReq q = {rm0, rn0, rk * BK, rt < ntiles};
-    if (q.valid && ++rk == ksteps) {
-      rk = 0;
-      rt += nwg;
-      if (rt < ntiles) coords(rt, rm0, rn0);
-    }
-    return q;
-  };
-  auto piece = [&](const StageReq& q, char* buf, int j) {   // this wave's request j (0..7) of a stage: tile j >> 1, instruction j & 1
-    const int tile = j >> 1, ins = wave * 2 + (j & 1);
-    if (tile < 2) stage_one_v<A_KM>(ra, buf + tile * TILE_BYTES, p.lda, q.m0 + tile * 128, q.k0, ins, lane, q.valid);
-    else stage_one_v<B_KM>(rb, buf + tile * TILE_BYTES, p.ldb, q.n0 + (tile - 2) * 128, q.k0, ins, lane, q.valid);
-  };
-  {
-    const StageReq q0 = next_stage();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) piece(q0, smem, j);
-    const StageReq q1 = next_stage();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) piece(q1, smem + BUF, j);
-  }
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int cur = 0;
-  const int bcol = (wc & 1) * 64;
-
-  while (true) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < ksteps; ++kt) {
-      const bool last = kt + 1 == ksteps;
-      char* bufc = smem + cur * BUF;
-      const char* ta = bufc + wr * TILE_BYTES;
-      const char* tb = bufc + (2 + (wc >> 1)) * TILE_BYTES;
-      bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = load_frag<B_KM>(tb, bcol + j * 16, ks, lane);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = load_frag<B_KM>(tb, bcol + 32 + j * 16, ks, lane);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[i][2 + j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[i][ks] = load_frag<A_KM>(ta, 64 + i * 16, ks, lane);
-      // ---- mid-step barrier: every wave has made its last read of this buffer -> it can be refilled half a step early
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      StageReq rq = {0, 0, 0, 0};
-      const bool pending = !last;                       // a tile's last step leaves the buffer to the epilogue
-      if (pending) rq = next_stage();
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j][ks], fa[i][ks], acc[4 + i][2 + j], 0, 0, 0);
-            if (j == 1 && (i & 1) && pending) piece(rq, bufc, ks * 2 + (i >> 1));
-          }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
-            if (j == 1 && (i & 1) && pending) piece(rq, bufc, 4 + ks * 2 + (i >> 1));
-          }
-      // ---- end of step: the OTHER buffer (requested 1.5 steps ago) must have landed; this step's own requests stay in flight
-      if (pending) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur ^= 1;
-    }
-    char* wl = smem + (cur ^ 1) * BUF + wave * 8192;     // the buffer of the last step: no request was sent into it
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
-    wave_epilogue_64x64<true>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
-    t += nwg;
-    if (t >= ntiles) break;
-    coords(t, m0, n0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // all epilogue scratch reads done
-    const StageReq rq = next_stage();                    // the request the last step deferred
-#pragma unroll
-    for (int j = 0; j < 8; ++j) piece(rq, smem + (cur ^ 1) * BUF, j);
-  }
-}
-
-template <bool A_KM, bool B_KM>
-int launch256_early(GemmParams p, hipStream_t stream) {
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      sa_set_error("sa_gemm_bf16: cannot query the device");
-      return 2;
-    }
-    slots = prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_early_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              8 * TILE_BYTES);
-  }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm256_early_kernel<A_KM, B_KM>), dim3(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots)), dim3(512), 8 * TILE_BYTES, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(256 early)");
-  return 0;
-}
-
 template <bool A_KM, bool B_KM, bool SWAP>
 int launch(const GemmParams& p, hipStream_t stream) {
   const int nwg = p.tiles_m * p.tiles_n * p.split_k;
@@ -1506,15 +861,6 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
 }
 
 }  // namespace
-
-extern "C" int sa_gemm_debug_counters(uint64_t* out16) {
-  if (hipDeviceSynchronize() != hipSuccess ||
-      hipMemcpyFromSymbol(out16, HIP_SYMBOL(sa_gemm_prof), 16 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost) != hipSuccess) {
-    sa_set_error("sa_gemm_debug_counters: copy failed");
-    return 2;
-  }
-  return 0;
-}
 
 namespace {
 // out[n] += sum over the rows of ws[rows][N]; 16 waves split the rows, lanes are columns
@@ -1653,22 +999,16 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // forward + dgrad shapes: scripts/bench_gemm.py); small / ragged problems use the plain 128 x 128 kernel.
   // mode 8 (five-slot half-stage ring, requests trickled between MFMAs) measured 8-13 % faster than mode 6 on the dgrad (NN,
   // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
-  char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1');
-  if (mode == '2' && p.colsum_ws) mode = '6';   // the plain 256^2 kernel has its own epilogue without the column-sum hook
-  if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4 && !(p.epi_kind == 5 && !p.colsum_ws && false)) {
+  // mode A (phased kernel, gemm_phase.hip): measured faster than mode 6 on the forward layout with the bias + residual -> fp32
+  // epilogue (proj 150 vs 163 us, fc2 305 vs 343 us) and equal or slower elsewhere (scripts/bench_gemm.py): default there only.
+  char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : ((a->a_kmajor && p.epi_kind == 3 && a->K >= 2 * BK) ? 'A' : '6')) : '1');
+  if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     const int rc = sagemm::launch_phase(p, a->a_kmajor, a->b_kmajor, false, stream);
     if (rc >= 0) return rc;
     mode = (a->a_kmajor && !a->b_kmajor) ? '8' : '6';
   } else if (mode == 'A' && a->split_k == 1) {
     mode = big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : '6') : '1';
-  }
-  if (mode == '9' && a->split_k == 1) {
-    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
-    if (a->a_kmajor && a->b_kmajor) return launch256_early<true, true>(p, stream);
-    if (a->a_kmajor && !a->b_kmajor) return launch256_early<true, false>(p, stream);
-    if (!a->a_kmajor && a->b_kmajor) return launch256_early<false, true>(p, stream);
-    return launch256_early<false, false>(p, stream);
   }
   if (mode == '8' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
@@ -1677,39 +1017,12 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     if (!a->a_kmajor && a->b_kmajor) return launch256_ring<false, true, false>(p, stream);
     return launch256_ring<false, false, false>(p, stream);
   }
-  if (mode == '7' && a->split_k == 1 && a->K >= 128) {
-    if (a->a_kmajor && a->b_kmajor) return launch256_pp<true, true>(p, stream);
-    if (a->a_kmajor && !a->b_kmajor) return launch256_pp<true, false>(p, stream);
-    if (!a->a_kmajor && a->b_kmajor) return launch256_pp<false, true>(p, stream);
-    return launch256_pp<false, false>(p, stream);
-  }
   if (mode == '6' && a->split_k == 1) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     if (a->a_kmajor && a->b_kmajor) return launch256_persist<true, true>(p, stream);
     if (a->a_kmajor && !a->b_kmajor) return launch256_persist<true, false>(p, stream);
     if (!a->a_kmajor && a->b_kmajor) return launch256_persist<false, true>(p, stream);
     return launch256_persist<false, false>(p, stream);
-  }
-  if (mode == '5' && a->split_k == 1) {
-    if (a->a_kmajor && a->b_kmajor) return launch_persist<true, true>(p, stream);
-    if (a->a_kmajor && !a->b_kmajor) return launch_persist<true, false>(p, stream);
-    if (!a->a_kmajor && a->b_kmajor) return launch_persist<false, true>(p, stream);
-    return launch_persist<false, false>(p, stream);
-  }
-  if (mode == '3' && a->split_k == 1) {
-    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
-    if (a->a_kmajor && a->b_kmajor) return launch_p3<true, true>(p, stream);
-    if (a->a_kmajor && !a->b_kmajor) return launch_p3<true, false>(p, stream);
-    if (!a->a_kmajor && a->b_kmajor) return launch_p3<false, true>(p, stream);
-    return launch_p3<false, false>(p, stream);
-  }
-  if (mode == '2' && a->split_k == 1) {
-    // the 256-wide tile reads up to 256 rows past the last valid one: keep the descriptor range check honest
-    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
-    if (a->a_kmajor && a->b_kmajor) return launch256<true, true>(p, stream);
-    if (a->a_kmajor && !a->b_kmajor) return launch256<true, false>(p, stream);
-    if (!a->a_kmajor && a->b_kmajor) return launch256<false, true>(p, stream);
-    return launch256<false, false>(p, stream);
   }
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");

@@ -246,14 +246,18 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
 // Mirror of staged_store_bf16 for an epilogue INPUT: a row-per-lane read of aux_in touches 16 rows x 32 B per instruction (a quarter
 // of every 128-byte line it pulls in); going through the wave's LDS scratch reads whole 128-byte row segments instead.  Swizzled layout only.
 template <int NI = 4>
-__device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds, const bf16_t* src, int64_t ld, int m_base, int n_base, int lane) {
+__device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds, const bf16_t* src, int64_t ld, int m_base, int n_base, int lane,
+                                                 const uint4* pre = nullptr) {
+  // pre: the 2 * NI row segments of this lane, already loaded by the caller (all of a tile's epilogue inputs are requested in one
+  // batch before its first store: a load issued after a store waits for that store in the in-order vmcnt queue)
   const int ch = lane & 7;
 #pragma unroll
   for (int it = 0; it < 2 * NI; ++it) {
     const int r = it * 8 + (lane >> 3);
     const int m = m_base + r;
     uint4 val = make_uint4(0u, 0u, 0u, 0u);
-    if (m < p.M) val = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + n_base + ch * 8);
+    if (pre) val = pre[it];
+    else if (m < p.M) val = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + n_base + ch * 8);
     *reinterpret_cast<uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4)) = val;
   }
 }
@@ -271,7 +275,9 @@ __device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds
 // `csacc` (CSM 1: first half, keep the sums; CSM 2: second half, add and write the workspace row; CSM 0: whole block at once).
 template <bool SWZ, int kind, int NI = 4, int CSM = 0>
 __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4 (&acc)[NI][4], int m_base, int n_base, char* wlds, int lane,
-                                                      float (*csacc)[4] = nullptr) {
+                                                      float (*csacc)[4] = nullptr, const float4* bias4 = nullptr, const uint4* aux_pre = nullptr) {
+  // bias4: the four float4 of this lane's bias columns, loaded ONCE per tile by the caller.  A load inside this function sits
+  // behind the previous call's stores in the in-order vmcnt queue, so waiting for it drains them (an HBM round trip per call).
   if (n_base >= p.N) return;                    // N is a multiple of 64 here: a 64-column block is wholly inside or wholly outside
   const int g = lane >> 4, c = lane & 15;
   const float alpha = p.alpha;
@@ -279,7 +285,8 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
+      if (bias4) b = bias4[j];
+      else if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + 4 * g);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         acc[i][j][0] = acc[i][j][0] * alpha + b.x; acc[i][j][1] = acc[i][j][1] * alpha + b.y;
@@ -305,22 +312,34 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
     }
     staged_store_bf16<SWZ, 0, NI>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
   } else if constexpr (kind == 3) {
+    // residual and output may alias as far as the compiler knows, so a load written after a store stays after it -- and waiting
+    // for that load (the youngest op, vmcnt(0)) then waits for the store as well: 32 serialised HBM round trips per tile.  All
+    // eight residual loads of a 32-row group go out first, then the eight stores.
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int m = m_base + i * 16 + c;
-      if (m >= p.M) continue;
-      const float* rrow = p.residual + (int64_t)m * p.ldr + n_base + 4 * g;
-      float* orow = p.out_f32 + (int64_t)m * p.ldo_f32 + n_base + 4 * g;
+    for (int i0 = 0; i0 < NI; i0 += 2) {
+      float4 rv[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 rv = *reinterpret_cast<const float4*>(rrow + j * 16);
-        *reinterpret_cast<float4*>(orow + j * 16) =
-            make_float4(acc[i][j][0] + rv.x, acc[i][j][1] + rv.y, acc[i][j][2] + rv.z, acc[i][j][3] + rv.w);
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = m_base + (i0 + ii) * 16 + c;
+        const float* rrow = p.residual + (int64_t)(m < p.M ? m : 0) * p.ldr + n_base + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rv[ii][j] = *reinterpret_cast<const float4*>(rrow + j * 16);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = i0 + ii;
+        const int m = m_base + i * 16 + c;
+        if (m >= p.M) continue;
+        float* orow = p.out_f32 + (int64_t)m * p.ldo_f32 + n_base + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(orow + j * 16) = make_float4(acc[i][j][0] + rv[ii][j].x, acc[i][j][1] + rv[ii][j].y,
+                                                                  acc[i][j][2] + rv[ii][j].z, acc[i][j][3] + rv[ii][j].w);
       }
     }
   } else {
     static_assert(SWZ, "the compact epilogues stage through the swizzled 8 KiB scratch");
-    staged_load_bf16<NI>(p, wlds, p.aux_in, p.ldaux, m_base, n_base, lane);
+    staged_load_bf16<NI>(p, wlds, p.aux_in, p.ldaux, m_base, n_base, lane, aux_pre);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int row = i * 16 + c;                       // rows past M were staged as zeros: their products are zero, nothing is stored

@@ -55,6 +55,10 @@ __device__ __forceinline__ bf16x8 ph_frag(const char* img, int sub0, int kstep, 
   }
 }
 
+#ifdef SA_PHASE_STAMPS
+__device__ unsigned long long sa_phase_prof[4][8];
+#endif
+
 template <bool A_KM, bool B_KM, bool SPLIT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,24 +169,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();                // wave row 1 runs one interval behind from here on
 
+  // SA_PHASE_STAMPS (scripts/microbench/gemm_phase_prof.hip only; never in the library): cycle stamps of every wave 0 / wave 4
+  // per segment -- [0] L issue (reads + requests), [1] vmcnt wait, [2] barrier 1, [3] lgkmcnt wait, [4] MFMA issue, [5] barrier 2
+#ifdef SA_PHASE_STAMPS
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter(), tnow;
+  const unsigned long long tbegin = tprev;
+#define PH_T(k) { __builtin_amdgcn_sched_barrier(0); tnow = __builtin_readcyclecounter(); pt[k] += tnow - tprev; tprev = tnow; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PH_T(k)
+#endif
 #define SA_MM(FA, FB, ACC) (SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA, FB, ACC, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB, FA, ACC, 0, 0, 0))
 #define SA_L_END()                                             \
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            \
+  PH_T(0)                                                      \
+  if (fresh) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + EPI_STORES) : "memory");   \
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");       \
   __builtin_amdgcn_sched_barrier(0);                           \
+  PH_T(1)                                                      \
   __builtin_amdgcn_s_barrier();                                \
+  PH_T(2)                                                      \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
   __builtin_amdgcn_sched_barrier(0);                           \
+  PH_T(3)                                                      \
   __builtin_amdgcn_s_setprio(1);
 #define SA_M_END()                                             \
   __builtin_amdgcn_s_setprio(0);                               \
   __builtin_amdgcn_sched_barrier(0);                           \
+  PH_T(4)                                                      \
   __builtin_amdgcn_s_barrier();                                \
-  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);                           \
+  PH_T(5)
 #define SA_QUAD(AI, BJ, FBX)                                                                       \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[AI + i][BJ + j] = SA_MM(fa[i][ks], FBX[j][ks], acc[AI + i][BJ + j]);
 
+  // vmcnt counts stores too, in issue order: right after an epilogue the counted wait would first drain the tile's stores
+  // (an HBM round trip) although everything the next phases read was requested BEFORE them.  For five phases after the epilogue
+  // of a FULL tile (its store count is then exact) the wait leaves those stores outstanding as well.
+  constexpr int EPI_STORES = SPLIT ? 0 : (EPI == 1 ? 16 : (EPI == 3 || EPI == 6) ? 32 : 0);
+  bool after_full = false;                                   // the previous unit of this workgroup stored a full 256 x 256 tile
   int sidx = 0;                                              // stream index of the K-tile being consumed (buffer = sidx & 1)
   while (true) {
     f32x4 acc[8][4];
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
     for (int kt = 0; kt < nk; ++kt, ++sidx) {
       const int buf = sidx & 1;
       const char* cur = smem + buf * PH_BUF;
+      bool fresh = EPI_STORES > 0 && after_full && kt <= 1;
       // ---- P1: quadrant (A_lo, B_lo)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -207,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
       SA_L_END()
       SA_QUAD(0, 0, fb0)
       SA_M_END()
+      fresh = fresh && kt == 0;
       // ---- P2: quadrant (A_lo, B_hi)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -250,20 +277,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
     } else {
       char* wl = smem + 2 * PH_BUF + wave * 4096;
       float cs[4][4];
+      const int nb = n0 + wc * 64;
+      float4 bias4[4];                                   // once per tile: later loads would queue behind the tile's stores
+      const bool has_bias = (EPI == 1 || EPI == 3 || EPI == 6) && p.bias != nullptr && nb < p.N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bias4[j] = has_bias ? *reinterpret_cast<const float4*>(p.bias + nb + j * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      uint4 auxv[(EPI == 5) ? 16 : 1];                   // kind 5: the tile's whole aux_in block of this wave (128 rows x 64 columns)
+      if constexpr (EPI == 5) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + wr * 128 + q * 8 + (lane >> 3);
+          auxv[q] = (m < p.M && nb < p.N) ? *reinterpret_cast<const uint4*>(p.aux_in + (int64_t)m * p.ldaux + nb + (lane & 7) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         f32x4(&blk)[2][4] = reinterpret_cast<f32x4(&)[2][4]>(acc[2 * h]);
-        const int mb = m0 + wr * 128 + h * 32, nb = n0 + wc * 64;
-        if (h & 1) wave_epilogue_compact<true, EPI, 2, 2>(p, blk, mb, nb, wl, lane, cs);
-        else wave_epilogue_compact<true, EPI, 2, 1>(p, blk, mb, nb, wl, lane, cs);
+        const int mb = m0 + wr * 128 + h * 32;
+        const uint4* pre = (EPI == 5) ? &auxv[4 * h] : nullptr;
+        if (h & 1) wave_epilogue_compact<true, EPI, 2, 2>(p, blk, mb, nb, wl, lane, cs, bias4, pre);
+        else wave_epilogue_compact<true, EPI, 2, 1>(p, blk, mb, nb, wl, lane, cs, bias4, pre);
       }
     }
+    PH_T(6)
+    after_full = m0 + 256 <= p.M && n0 + 256 <= p.N;
     u += nwg;
     if (u >= nunits) break;
     unit(u, m0, n0, kt0, nk);
   }
+#ifdef SA_PHASE_STAMPS
+  if ((blockIdx.x == 0 || blockIdx.x == 133) && (threadIdx.x & 255) == 0) {     // waves 0 and 4 of two workgroups
+    unsigned long long* o = sa_phase_prof[(blockIdx.x == 0 ? 0 : 2) + wr];
+    for (int k = 0; k < 7; ++k) o[k] = pt[k];
+    o[7] = __builtin_readcyclecounter() - tbegin;
+  }
+#endif
   if (wr == 0) __builtin_amdgcn_s_barrier();                // pairs with row 1's extra barrier
 #undef SA_MM
+#undef PH_T
 #undef SA_L_END
 #undef SA_M_END
 #undef SA_QUAD

@@ -383,6 +383,56 @@ def mae_recon_loss_bwd(pred, row0, img, mask, ph, pw, acc2, gscale, dpred):
                                       B, F_, T_, ph, pw, _p(_req(dpred, F32, "dpred")), _stream()), "sa_mae_recon_loss_bwd")
 
 
+# ------------------------------------------------------------------------------------------------ convolutional stems (NHWC)
+def conv_out_size(n, stride):
+    """3x3 kernel, padding 1."""
+    return (n - 1) // stride + 1
+
+
+def conv3x3_c1_fwd(x, w, bias, stride, y):
+    """x fp32 [B, 1, H, W] (or [B, H, W]) -> y fp32 [B*Ho*Wo, C_out] (NHWC rows)."""
+    B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    check(lib().sa_conv3x3_c1_fwd(_p(_req(x, F32, "x")), B, H, W, stride[0], stride[1], _p(_req(w, F32, "w")), _p(bias), w.shape[0],
+                                  _p(_req(y, F32, "y")), _stream()), "sa_conv3x3_c1_fwd")
+
+
+def conv3x3_c1_wgrad(x, dy16, stride, dw, dbias=None):
+    B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    check(lib().sa_conv3x3_c1_wgrad(_p(_req(x, F32, "x")), B, H, W, stride[0], stride[1], _p(_req(dy16, BF16, "dy")), dy16.shape[-1],
+                                    _p(_req(dw, F32, "dw")), _p(dbias), _stream()), "sa_conv3x3_c1_wgrad")
+
+
+def im2col3x3(x16, B, H, W, C, stride, out):
+    check(lib().sa_im2col3x3_bf16(_p(_req(x16, BF16, "x")), B, H, W, C, stride[0], stride[1], _p(_req(out, BF16, "out")), out.shape[-1], _stream()),
+          "sa_im2col3x3_bf16")
+
+
+def col2im3x3(dP16, B, H, W, C, stride, dx):
+    check(lib().sa_col2im3x3_f32(_p(_req(dP16, BF16, "dP")), B, H, W, C, stride[0], stride[1], dP16.shape[-1], _p(_req(dx, F32, "dx")), _stream()),
+          "sa_col2im3x3_f32")
+
+
+def bn_colstats_tall(x, mean, m2):
+    M, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    ws = _workspace(lib().sa_bn_tall_workspace_bytes(M, Cn), x.device, "bn_tall")
+    check(lib().sa_bn_colstats_tall(_p(x), ld, M, Cn, _p(ws), _p(mean), _p(m2), _stream()), "sa_bn_colstats_tall")
+
+
+def bn_bwd_stats_tall(dy, x, mean, rstd, gamma, beta, relu, s1, s2):
+    M, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    ws = _workspace(lib().sa_bn_tall_workspace_bytes(M, Cn), x.device, "bn_tall")
+    check(lib().sa_bn_bwd_stats_tall(_p(dy), int(dy.dtype == BF16), _rows(dy, "dy")[2], _p(x), ld, M, Cn, _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                     int(relu), _p(ws), _p(s1), _p(s2), _stream()), "sa_bn_bwd_stats_tall")
+
+
+def maxpool2_fwd(x16, B, H, W, C, y16, idx):
+    check(lib().sa_maxpool2_fwd(_p(_req(x16, BF16, "x")), B, H, W, C, _p(_req(y16, BF16, "y")), _p(idx), _stream()), "sa_maxpool2_fwd")
+
+
+def maxpool2_bwd(dy, idx, B, H, W, C, dx):
+    check(lib().sa_maxpool2_bwd(_p(_req(dy, F32, "dy")), _p(idx), B, H, W, C, _p(_req(dx, F32, "dx")), _stream()), "sa_maxpool2_bwd")
+
+
 def device_info():
     name = C.create_string_buffer(128)
     cus = C.c_int32(0)
