@@ -163,8 +163,35 @@ def block(x, p, pre, num_heads):
     return x + R.qb(F.linear(h, R.qw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]))
 
 
-def patch_embed(x, p):
-    """PatchEmbed.forward (models/mae.py:40-43)."""
+CONVSTEM_STRIDES = {  # models/mae.py:58-67
+    (16, 16): [(2, 2)] * 4,
+    (16, 8): [(2, 2)] * 3 + [(2, 1)],
+    (8, 8): [(2, 2)] * 3 + [(1, 1)],
+    (64, 2): [(2, 2)] + [(2, 1)] * 5,
+}
+
+
+def conv_stem(x, p, patch, bn_stats=None):
+    """ConvStem.forward (models/mae.py:89-99): [3x3 conv (no bias) -> BatchNorm2d (train mode: batch statistics) -> ReLU] per
+    stride entry, then a 1x1 conv with bias; tokens = flatten(2).transpose(1, 2).  `bn_stats` (list) receives (mean, biased var, n)
+    per BatchNorm for the running-statistics replay.  Hooks: operands of every conv are bf16 on the HIP path (R.qf / R.qw), the
+    pre-BatchNorm maps are fp32 with bf16 gradients (R.qb)."""
+    strides = CONVSTEM_STRIDES[tuple(patch)]
+    h = x
+    for l, st in enumerate(strides):
+        h = R.qb(F.conv2d(R.qf(h), R.qw(p[f"patch_embed.proj.{3 * l}.weight"]), None, stride=st, padding=1))
+        if bn_stats is not None:
+            bn_stats.append((h.mean((0, 2, 3)).detach(), h.var((0, 2, 3), unbiased=False).detach(), h.numel() // h.shape[1]))
+        h = F.relu(F.batch_norm(h, None, None, p[f"patch_embed.proj.{3 * l + 1}.weight"], p[f"patch_embed.proj.{3 * l + 1}.bias"], True, 0.1, 1e-5))
+    last = 3 * len(strides)
+    h = R.qb(F.conv2d(R.qf(h), R.qw(p[f"patch_embed.proj.{last}.weight"]), p[f"patch_embed.proj.{last}.bias"]))
+    return h.flatten(2).transpose(1, 2)
+
+
+def patch_embed(x, p, patch=None, bn_stats=None):
+    """PatchEmbed.forward (models/mae.py:40-43), or ConvStem.forward when the parameters are a conv stem's."""
+    if "patch_embed.proj.0.weight" in p:
+        return conv_stem(x, p, patch, bn_stats)
     w = p["patch_embed.proj.weight"]
     return F.conv2d(R.qf(x), R.qw(w), p["patch_embed.proj.bias"], stride=w.shape[-2:]).flatten(2).transpose(1, 2)
 
@@ -189,21 +216,22 @@ def masking_from_noise(x, noise=None, mask=None, mask_ratio=0.0):
     return x_masked, torch.gather(m, 1, ids_restore), ids_restore
 
 
-def prepare_tokens(x, p, grid, noise=None, mask=None, mask_ratio=0.0):
-    """prepare_tokens (models/mae.py:349-365)."""
+def prepare_tokens(x, p, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None):
+    """prepare_tokens (models/mae.py:349-365).  `patch` = patch size, required for a conv stem (a PatchEmbed carries it in its kernel)."""
     B, _, Fb, T = x.shape
-    pw = p["patch_embed.proj.weight"]
-    tok = patch_embed(x, p)
-    pos = torch.from_numpy(interpolate_pos_embed(p["pos_embed"].detach().numpy(), grid, Fb, T, tuple(pw.shape[-2:]))).to(x.dtype)
+    if patch is None:
+        patch = tuple(p["patch_embed.proj.weight"].shape[-2:])
+    tok = patch_embed(x, p, patch, bn_stats)
+    pos = torch.from_numpy(interpolate_pos_embed(p["pos_embed"].detach().numpy(), grid, Fb, T, tuple(patch))).to(x.dtype)
     tok = tok + pos[:, 1:]
     tok, m, ids_restore = masking_from_noise(tok, noise, mask, mask_ratio)
     cls = (p["cls_token"] + p["pos_embed"][:, :1]).expand(B, -1, -1)
     return torch.cat((cls, tok), dim=1), m, ids_restore
 
 
-def forward_encoder(x, p, num_heads, grid, noise=None, mask=None, mask_ratio=0.0):
+def forward_encoder(x, p, num_heads, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None):
     """forward_encoder (models/mae.py:394-400)."""
-    tok, m, ids_restore = prepare_tokens(x, p, grid, noise, mask, mask_ratio)
+    tok, m, ids_restore = prepare_tokens(x, p, grid, noise, mask, mask_ratio, patch, bn_stats)
     for i in range(infer_arch(p)):
         tok = block(tok, p, f"blocks.{i}.", num_heads)
     C = tok.shape[-1]
@@ -239,9 +267,9 @@ def recon_loss(imgs, pred, mask, grid):
 
 
 def forward(x, p, num_heads, grid, mean_pool=False, noise=None, mask=None, mask_ratio=0.0,
-            masked_recon=False, dec_heads=6):
+            masked_recon=False, dec_heads=6, patch=None, bn_stats=None):
     """MaskedAutoencoderViT.forward (models/mae.py:455-469)."""
-    enc, m, ids_restore = forward_encoder(x, p, num_heads, grid, noise, mask, mask_ratio)
+    enc, m, ids_restore = forward_encoder(x, p, num_heads, grid, noise, mask, mask_ratio, patch, bn_stats)
     latent = enc[:, 1:].mean(dim=1) if mean_pool else enc[:, 0]
     if masked_recon:
         pred = forward_decoder(enc, ids_restore, p, dec_heads)

@@ -3,8 +3,8 @@ signature as the reference's models/mae.py:166-469, so checkpoints and call site
 
 The nn.Module tree below only *owns parameters* (identical names / shapes / init families as the reference);
 no submodule's forward is ever called.  Compute is the explicit HIP schedule in engine.py / functional.py.
-Not provided (out of this path's scope): ConvStem (`vitc_*`), learned positional embedding,
-norm_pix_loss, forward_attn / forward_viz.
+The `vitc_*` variants put the ConvStem (convstem.py) in place of the patch projection.
+Not provided (out of this path's scope): learned positional embedding, norm_pix_loss, forward_attn / forward_viz.
 """
 from functools import partial
 
@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import ops
+from .convstem import ConvStem, ConvStemTokensFn, stem_flat_params
 from .engine import encoder_apply
 from .pos_embed import get_2d_sincos_pos_embed, get_sinusoid_encoding_table, interpolate_pos_encoding
 
@@ -79,8 +80,6 @@ class MaskedAutoencoderViT(nn.Module):
                  block_cls=BlockKBiasZero, use_2d_dec_pos_embd=False,
                  drop_path_rate=0.):
         super().__init__()
-        if conv_stem:
-            raise NotImplementedError("ConvStem (vitc_*) encoders are outside the MI355X hot path (SURVEY.md §2)")
         if use_learned_pos_embd or norm_pix_loss or drop_path_rate:
             raise NotImplementedError("learned pos-embed / norm_pix_loss / drop_path are not on the MI355X hot path")
         if in_chans != 1:
@@ -92,9 +91,12 @@ class MaskedAutoencoderViT(nn.Module):
         self.num_heads, self.decoder_num_heads = num_heads, decoder_num_heads
         self.ln_eps = norm_layer(8).eps
 
-        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
-        for param in self.patch_embed.parameters():      # random patch projection, frozen (models/mae.py:190-192)
-            param.requires_grad = False
+        if conv_stem:                                        # trained, unlike the plain patch projection (models/mae.py:186-192)
+            self.patch_embed = ConvStem(img_size, patch_size, in_chans, embed_dim)
+        else:
+            self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+            for param in self.patch_embed.parameters():      # random patch projection, frozen (models/mae.py:190-192)
+                param.requires_grad = False
         total_patches = self.patch_embed.num_patches + 1
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, total_patches, embed_dim), requires_grad=False)
@@ -134,8 +136,9 @@ class MaskedAutoencoderViT(nn.Module):
             else:
                 dpos = get_sinusoid_encoding_table(self.grid_size()[0] * self.grid_size()[1], self.decoder_pos_embed.shape[-1])
             self.decoder_pos_embed.data.copy_(torch.from_numpy(dpos).float().unsqueeze(0))
-        w = self.patch_embed.proj.weight.data
-        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        if not self.conv_stem:                               # the conv stem keeps nn.Conv2d's default initialisation (models/mae.py:260)
+            w = self.patch_embed.proj.weight.data
+            torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
         torch.nn.init.normal_(self.cls_token, std=.02)
         if self.use_decoder:
             torch.nn.init.normal_(self.mask_token, std=.02)
@@ -198,7 +201,10 @@ class MaskedAutoencoderViT(nn.Module):
             ids_restore = torch.arange(L, device=x.device).to(torch.int)
         else:
             ids_keep, mask, ids_restore = self.masking_indices(B, L, mask_ratio, x.device, noise)
-        tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep)
+        if self.conv_stem:
+            tok = ConvStemTokensFn.apply(x, self.cls_token, pos, ids_keep, self.patch_embed, *stem_flat_params(self.patch_embed))
+        else:
+            tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep)
         return tok, mask, ids_restore
 
     def _run_blocks(self, tok, blocks, norm, heads, pool):
@@ -257,11 +263,27 @@ def mae_vit_large_patchX(patch_size, **kwargs):
     return _vit(patch_size, 1024, 24, 16, decoder_embed_dim=384, decoder_depth=4, decoder_num_heads=6, **kwargs)
 
 
+def mae_vitc_base_patchX(patch_size, **kwargs):
+    """ViTC-B (models/mae.py:531-537): 11 blocks behind the conv stem."""
+    return _vit(patch_size, 768, 11, 12, conv_stem=True, decoder_embed_dim=384, decoder_depth=4, decoder_num_heads=6, **kwargs)
+
+
+def mae_vitc_small_patchX(patch_size, **kwargs):
+    return _vit(patch_size, 384, 11, 6, conv_stem=True, **kwargs)
+
+
+def mae_vitc_tiny_patchX(patch_size, **kwargs):
+    return _vit(patch_size, 192, 11, 3, conv_stem=True, **kwargs)
+
+
 def get_mae_vit(size='base', patch_size=None, c=False, **kwargs):
     if patch_size is None:
         patch_size = [16, 16]
     if c:
-        raise NotImplementedError("ConvStem (vitc_*) encoders are outside the MI355X hot path (SURVEY.md §2)")
+        table = {'base': mae_vitc_base_patchX, 'small': mae_vitc_small_patchX, 'tiny': mae_vitc_tiny_patchX}
+        if size not in table:
+            raise NotImplementedError(f'Size {size} is not supported')
+        return table[size](patch_size, **kwargs)
     table = {'base': mae_vit_base_patchX, 'small': mae_vit_small_patchX, 'tiny': mae_vit_tiny_patchX, 'large': mae_vit_large_patchX}
     if size not in table:
         raise NotImplementedError(f'Size {size} is not supported')

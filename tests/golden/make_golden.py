@@ -542,7 +542,43 @@ def gen_eval():
     save("eval", **out)
 
 
+def gen_convstem():
+    """ConvStem ViTC (models/mae.py:46-99, conv_stem=True): micro encoder (d=128, 2 blocks, 2 heads; stem channels 16/32/64/128) with
+    16x16 and 16x8 patches, train mode (BatchNorm2d on batch statistics): tokens, latent, gradients of every stem parameter, and the
+    BatchNorm running statistics after the forward."""
+    out = {}
+    for tag, patch, T_ in [("p16x16_t96", [16, 16], 96), ("p16x8_t96", [16, 8], 96), ("p16x16_t208", [16, 16], 208)]:
+        torch.manual_seed(0)
+        m = ref_mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=patch, in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                         norm_layer=partial(nn.LayerNorm, eps=1e-6), conv_stem=True)
+        perturb_(m, 4)
+        m.train()
+        for k, v in m.state_dict().items():
+            out[f"{tag}_sd." + k] = t2n(v)
+        torch.manual_seed(12)
+        x = torch.randn(3, 1, 64, T_)
+        tok, _, _ = m.prepare_tokens(x, 0)
+        out[f"{tag}_x"], out[f"{tag}_tokens"] = t2n(x), t2n(tok)
+        m.load_state_dict({k[len(f"{tag}_sd."):]: torch.from_numpy(v) for k, v in out.items() if k.startswith(f"{tag}_sd.")})   # undo the BN update
+        lat = m(x)
+        out[f"{tag}_latent"] = t2n(lat)
+        m.zero_grad()
+        w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+        (lat * w).sum().backward()
+        for n, prm in m.named_parameters():
+            if n.startswith("patch_embed.") or n in ("cls_token", "blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.weight"):
+                out[f"{tag}_grad.{n}"] = t2n(prm.grad)
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"{tag}_after." + k] = t2n(v)
+        out[f"{tag}_patch"] = np.array(patch)
+    save("convstem", **out)
+
+
 if __name__ == "__main__":
+    gen_convstem() if "convstem" in sys.argv[1:] else None
+    if len(sys.argv) > 1:
+        sys.exit(0)
     gen_bt_loss()
     gen_augment()
     gen_vit()

@@ -337,3 +337,34 @@ def test_gaussian_noise_and_running_norm_oracle_golden(golden):
     for i in range(5):
         np.testing.assert_allclose(rn(g[f"rn_x{i}"]), g[f"rn_y{i}"], rtol=2e-5, atol=2e-6, err_msg=f"sample {i}")
     np.testing.assert_allclose(rn.mu, g["rn_mean"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["p16x16_t96", "p16x8_t96", "p16x16_t208"])
+def test_convstem_oracle_golden(golden, tag):
+    """oracle.vit.conv_stem (models/mae.py:46-99) inside the encoder: tokens, latent and every captured gradient of the reference's
+    micro ViTC, fp32: 1e-5 (bit-exact at the constructor width, interpolation rounding at T = 208)."""
+    from oracle import vit as ovit
+    g = golden("convstem")
+    sd = {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + "_sd.")}
+    patch = tuple(int(v) for v in g[tag + "_patch"])
+    x = torch.from_numpy(g[tag + "_x"])
+    grid = (4, 96 // patch[1])
+    names = [k for k in sd if not ("running" in k or "num_batches" in k or k == "pos_embed")]
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    tok, _, _ = ovit.prepare_tokens(x, leaf, grid, patch=patch)
+    st = []
+    lat = ovit.forward(x, leaf, 2, grid, patch=patch, bn_stats=st)
+    assert float((tok.detach() - torch.from_numpy(g[tag + "_tokens"])).abs().max()) < 1e-5
+    assert float((lat.detach() - torch.from_numpy(g[tag + "_latent"])).abs().max()) < 1e-5
+    w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+    gs = dict(zip(names, torch.autograd.grad((lat * w).sum(), [leaf[k] for k in names], allow_unused=True)))
+    for k, v in g.items():
+        if k.startswith(tag + "_grad."):
+            ref = torch.from_numpy(v)
+            assert float((gs[k[len(tag) + 6:]] - ref).norm() / (ref.norm() + 1e-30)) < 1e-5, k
+    # BatchNorm running statistics replayed from the recorded batch statistics (momentum 0.1, unbiased variance)
+    for l, (mu, var, n) in enumerate(st):
+        rm = 0.9 * sd[f"patch_embed.proj.{3 * l + 1}.running_mean"] + 0.1 * mu
+        rv = 0.9 * sd[f"patch_embed.proj.{3 * l + 1}.running_var"] + 0.1 * var * n / (n - 1)
+        np.testing.assert_allclose(rm.numpy(), g[f"{tag}_after.patch_embed.proj.{3 * l + 1}.running_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(rv.numpy(), g[f"{tag}_after.patch_embed.proj.{3 * l + 1}.running_var"], rtol=1e-4, atol=1e-6)
