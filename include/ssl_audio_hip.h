@@ -171,8 +171,10 @@ int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32
 int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_slot, const int32_t* mix_slot, const float* params,
                      float* out, int32_t n_views, int32_t F_in, int32_t T_in, int32_t canvas_h, int32_t canvas_w, int32_t F_out,
                      int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream);
-/* NormalizeBatch (augmentations.py:229-232) over n contiguous floats; workspace2 = 2 doubles; shift ~ mean guess */
-int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream);
+/* NormalizeBatch (augmentations.py:229-232) over n contiguous floats; workspace2 = 2 doubles; shift ~ mean guess.
+ * stat_div = 1 is NormalizeBatch and the HEAR scene normalisation (hear/sample/vit.py:97-100); stat_div = number of frames
+ * reproduces hear/utils.py:36-53, which divides BOTH statistics by len(melspec) before (x - mean) / std (hear/sample/vit.py:203-205) */
+int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, float stat_div, void* stream);
 /* MixGaussianNoise (augmentations.py:125-141): out = log((1 - lambd) * exp(x) + exp(lambd * normal) + eps); `normal` holds the
  * caller's N(0,1) draws (torch.normal(0, lambd) == lambd * N(0,1)). */
 int sa_mix_gaussian_noise(const float* x, const float* normal, int64_t n, float lambd, float eps, float* out, void* stream);

@@ -34,22 +34,31 @@ def n_frames(n_samples, hop=160):
     return 1 + n_samples // hop
 
 
-def power_spectrogram(wave, n_fft=1024, hop=160, dtype=np.float64):
+def stft_window(n_fft, win_length=None, dtype=np.float64):
+    """torch.stft's window: periodic Hann of win_length, zero-padded on both sides to n_fft when shorter (hear/config.yaml: 400)."""
+    win_length = win_length or n_fft
+    w = np.zeros(n_fft, dtype=dtype)
+    left = (n_fft - win_length) // 2
+    w[left:left + win_length] = hann_periodic(win_length, dtype)
+    return w
+
+
+def power_spectrogram(wave, n_fft=1024, hop=160, dtype=np.float64, win_length=None):
     """wave [..., L] -> |STFT|^2 [..., n_fft//2+1, frames]; center=True reflect padding."""
     wave = np.asarray(wave, dtype=dtype)
     pad = n_fft // 2
     x = np.pad(wave, [(0, 0)] * (wave.ndim - 1) + [(pad, pad)], mode="reflect")
     T = n_frames(wave.shape[-1], hop)
     idx = np.arange(n_fft)[None, :] + hop * np.arange(T)[:, None]
-    frames = x[..., idx] * hann_periodic(n_fft, dtype)
+    frames = x[..., idx] * stft_window(n_fft, win_length, dtype)
     spec = np.fft.rfft(frames, axis=-1)
     p = spec.real ** 2 + spec.imag ** 2
     return np.swapaxes(p, -1, -2)
 
 
-def logmel(wave, n_fft=1024, hop=160, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, dtype=np.float64):
+def logmel(wave, n_fft=1024, hop=160, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, dtype=np.float64, win_length=None):
     """wave [..., L] -> log-mel [..., n_mels, frames]  (datasets.py:39-48,115)."""
-    p = power_spectrogram(wave, n_fft, hop, dtype)
+    p = power_spectrogram(wave, n_fft, hop, dtype, win_length)
     fb = mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate).astype(dtype)
     mel = np.einsum("...ft,fm->...mt", p, fb)
     return np.log(mel + EPS32)

@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 }
 
 __global__ void normalize_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float shift, const double* __restrict__ acc,
-                                       float eps) {
+                                       float eps, float stat_div) {
   const double s = acc[0], q = acc[1];
   const double mean_d = s / (double)n;
   const double var = (q - s * mean_d) / (double)(n - 1);
-  const float mean = (float)mean_d + shift;
-  const float stdv = fmaxf((float)sqrt(var > 0.0 ? var : 0.0), eps);
+  const float mean = ((float)mean_d + shift) / stat_div;
+  const float stdv = fmaxf((float)sqrt(var > 0.0 ? var : 0.0) / stat_div, eps);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = (x[i] - mean) / stdv;
 }
 
@@ -239,8 +239,8 @@ extern "C" int sa_running_norm(const float* x, int32_t channels, int64_t per_cha
   return 0;
 }
 
-extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, void* stream) {
-  SA_CHECK_ARG(x && y && workspace2 && n > 1, "sa_normalize_batch: bad args");
+extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, float stat_div, void* stream) {
+  SA_CHECK_ARG(x && y && workspace2 && n > 1 && stat_div > 0.f, "sa_normalize_batch: bad args");
   if (hipMemsetAsync(workspace2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) {
     sa_set_error("sa_normalize_batch: memset failed");
     return 2;
@@ -248,7 +248,7 @@ extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shi
   int64_t want = (n + 256 * 16 - 1) / (256 * 16);
   const int grid = (int)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, shift, workspace2);
-  hipLaunchKernelGGL(normalize_apply_kernel, dim3(grid * 4), dim3(256), 0, (hipStream_t)stream, x, y, n, shift, workspace2, eps);
+  hipLaunchKernelGGL(normalize_apply_kernel, dim3(grid * 4), dim3(256), 0, (hipStream_t)stream, x, y, n, shift, workspace2, eps, stat_div);
   SA_LAUNCH_CHECK("sa_normalize_batch");
   return 0;
 }

@@ -26,12 +26,17 @@ def _mel_filterbank(n_freqs, f_min, f_max, n_mels, sample_rate):
     return np.maximum(0.0, np.minimum(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
 
 
-def build_tables(device, n_fft=1024, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000):
+def build_tables(device, n_fft=1024, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, win_length=None):
     """Window, FFT twiddles and compact mel weights as device tensors (built once, in float64, stored fp32)."""
     if n_fft != 1024 or n_mels != 64:
         raise NotImplementedError("the HIP frontend is specialised for n_fft=1024, n_mels=64 (reference defaults)")
+    win_length = win_length or n_fft
     k = np.arange(n_fft, dtype=np.float64)
-    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n_fft)  # torch.hann_window(periodic=True)
+    # torch.hann_window(win_length, periodic=True), centred in the n_fft frame when shorter (torch.stft pads it on both sides:
+    # hear/config.yaml has win_length 400 against the training recipe's 1024)
+    window = np.zeros(n_fft)
+    left = (n_fft - win_length) // 2
+    window[left:left + win_length] = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length, dtype=np.float64) / win_length)
     tw = np.stack([np.cos(2.0 * np.pi * k / n_fft), -np.sin(2.0 * np.pi * k / n_fft)], axis=1)
     fb = _mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
     lo = np.zeros(n_mels, dtype=np.int32)
@@ -58,9 +63,9 @@ class MelSpectrogram(torch.nn.Module):
 
     def __init__(self, sample_rate=16000, n_fft=1024, win_length=1024, hop_length=160, n_mels=64, f_min=60, f_max=7800, power=2):
         super().__init__()
-        if win_length != n_fft or power != 2:
-            raise NotImplementedError("only win_length == n_fft and power == 2 (the reference's settings) are supported")
-        self.cfg = dict(n_fft=n_fft, n_mels=n_mels, f_min=float(f_min), f_max=float(f_max), sample_rate=sample_rate)
+        if win_length > n_fft or power != 2:
+            raise NotImplementedError("only win_length <= n_fft and power == 2 (the reference's settings) are supported")
+        self.cfg = dict(n_fft=n_fft, n_mels=n_mels, f_min=float(f_min), f_max=float(f_max), sample_rate=sample_rate, win_length=win_length)
         self.hop = hop_length
         self._tables = None
 

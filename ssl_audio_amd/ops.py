@@ -294,8 +294,8 @@ def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in,
                                  int(do_fade), _stream()), "sa_augment_views")
 
 
-def normalize_batch(x, y, shift, workspace, eps):
-    check(lib().sa_normalize_batch(_p(_req(x, F32, "x")), _p(y), x.numel(), float(shift), _p(workspace), float(eps), _stream()),
+def normalize_batch(x, y, shift, workspace, eps, stat_div=1.0):
+    check(lib().sa_normalize_batch(_p(_req(x, F32, "x")), _p(y), x.numel(), float(shift), _p(workspace), float(eps), float(stat_div), _stream()),
           "sa_normalize_batch")
 
 

@@ -1,0 +1,81 @@
+"""HEAR wrappers and checkpoint-key compatibility (hear/sample/vit.py:64-77,129-247, linear.py:114-133)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ssl_audio_amd import engine, hyperparameters as hp, ops  # noqa: E402
+from ssl_audio_amd.hear import utils as hutils, vit as hvit  # noqa: E402
+from ssl_audio_amd.train import BarlowTwinsTrainer  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    ops.lib()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_hear_scene_and_timestamp_embeddings_vs_oracle(dev):
+    """load_model(vit_tiny, 16x16) -> get_scene_embeddings / get_timestamp_embeddings on 1.7 s clips against oracle/hear.py with the
+    same weights: bf16 encoder tolerance 2e-2 (the reference's statistics quirk of hear/utils.py:47-50 included).  Mel arithmetic:
+    vs our restatement of torchaudio's spec (reference parity unpinned, as for the training frontend)."""
+    from oracle import hear as ohear
+    torch.manual_seed(0)
+    model = hvit.load_model("", "vit_tiny", "16x16")
+    assert model.scene_embedding_size == 192 and model.timestamp_embedding_size == 192 * 4 and model.sample_rate == 16000
+    g = torch.Generator().manual_seed(1)
+    audio = 0.3 * torch.randn(3, 27200, generator=g)
+    sd = {k: v.detach().cpu() for k, v in model.model.state_dict().items()}
+    scene = hvit.get_scene_embeddings(audio.to(dev), model)
+    ref = ohear.scene_embeddings(audio.numpy(), sd, 3, (4, 6), 96)
+    assert scene.shape == (3, 192) and rel(scene, ref) < 2e-2, rel(scene, ref)
+    emb, ts = hvit.get_timestamp_embeddings(audio.to(dev), model)
+    ref_e, ref_t = ohear.timestamp_embeddings(audio.numpy(), sd, 3, (4, 6), 96)
+    assert emb.shape == ref_e.shape and np.allclose(ts.numpy(), ref_t) and rel(emb, ref_e) < 2e-2, rel(emb, ref_e)
+    tsx = model._get_timestamps(audio, emb)
+    assert tsx.shape == (3, emb.shape[1])
+
+
+def test_checkpoint_keys_round_trip(dev):
+    """What main_bt_byol.py:492-503 saves ({'model': online.state_dict()}, DDP-prefixed or not) loads into (i) the HEAR wrapper
+    (hear/sample/vit.py:64-77), (ii) the linear-probe encoder (linear.py:114-133) and (iii) a FlatState-backed trainer, whose pinned
+    bf16 weight copies must follow the load (engine._Bf16Cache refreshes on the version bump): identical embeddings afterwards."""
+    from ssl_audio_amd import model as smodel
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128)
+    tr1 = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
+    g = torch.Generator().manual_seed(2)
+    views = [torch.randn(8, 1, 64, 96, generator=g).to(dev), torch.randn(8, 1, 64, 96, generator=g).to(dev)]
+    tr1.step_views(views)                                                 # weights now differ from any seed's initialisation
+    sd = tr1.online.state_dict()
+    with tempfile.TemporaryDirectory() as d:
+        for prefix in ("", "module."):
+            path = os.path.join(d, f"ckpt{len(prefix)}.pth")
+            torch.save({"model": {prefix + k: v for k, v in sd.items()}, "epoch": 1}, path)
+            wrapper = hvit.load_model(path, "vit_tiny", "16x16")
+            enc = smodel.ModelWrapper(cfg).encoder.to(dev)
+            hvit.load_encoder_state_dict(enc, torch.load(path, map_location="cpu"))
+            x = views[0]
+            with torch.no_grad():
+                a = tr1.online.backbone(x)
+                assert torch.equal(wrapper.model(x), a) and torch.equal(enc(x), a)
+    tr2 = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=8, clip_samples=15200, seed=5, from_waveform=False)
+    with torch.no_grad():
+        before = tr2.online(views, ncrops=2)
+    tr2.online.load_state_dict(sd)
+    with torch.no_grad():
+        z1, z2 = tr1.online(views, ncrops=2), tr2.online(views, ncrops=2)
+    assert not torch.equal(before, z2) and torch.equal(z1, z2)
+    p = dict(tr2.online.named_parameters())["backbone.encoder.encoder.blocks.3.mlp.fc1.weight"]
+    assert torch.equal(engine.BF16_WEIGHTS.get(p).float(), p.detach().to(torch.bfloat16).float())
+    l1, l2 = float(tr1.step_views(views)), float(tr2.step_views(views))   # and a step on the loaded weights runs
+    assert np.isfinite(l2) and abs(l1 - l2) <= 1e-5 * abs(l1)

@@ -368,3 +368,15 @@ def test_convstem_oracle_golden(golden, tag):
         rv = 0.9 * sd[f"patch_embed.proj.{3 * l + 1}.running_var"] + 0.1 * var * n / (n - 1)
         np.testing.assert_allclose(rm.numpy(), g[f"{tag}_after.patch_embed.proj.{3 * l + 1}.running_mean"], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(rv.numpy(), g[f"{tag}_after.patch_embed.proj.{3 * l + 1}.running_var"], rtol=1e-4, atol=1e-6)
+
+
+def test_hear_frame_audio_matches_the_reference_loop():
+    """ssl_audio_amd.hear.utils.frame_audio (vectorised) == the literal restatement of hear/utils.py:56-106 (oracle/hear.py)."""
+    from oracle import hear as ohear
+    from ssl_audio_amd.hear import utils as hutils
+    g = torch.Generator().manual_seed(0)
+    for n_samples, frame, hop in [(16000, 15200, 50.0), (27211, 15200, 50.0), (5000, 800, 12.5)]:
+        a = torch.randn(2, n_samples, generator=g)
+        fr, ts = hutils.frame_audio(a, frame, hop, 16000)
+        rf, rt = ohear.frame_audio(a.numpy(), frame, hop, 16000)
+        assert fr.shape == rf.shape and np.array_equal(fr.numpy(), rf) and np.allclose(ts.numpy(), rt)
