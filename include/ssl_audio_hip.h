@@ -252,6 +252,19 @@ int sa_bn_bwd_stats_tall(const void* dy, int32_t dy_is_bf16, int64_t lddy, const
  * backward routes dy (fp32) to that position and writes every element of dx [B][H][W][C] */
 int sa_maxpool2_fwd(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, void* y_bf16, uint8_t* idx, void* stream);
 int sa_maxpool2_bwd(const float* dy, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
+/* AudioNTT glue (model.py:153-191).  relu_mask: y = relu(x) [* keep * scale] (nn.ReLU, and nn.Dropout in train mode with the caller's
+ * keep mask: uint8 [M][C], scale = 1 / (1 - p)); backward dx = dy * [x_pre > 0] [* keep * scale] as bf16.  nhwc_to_frames:
+ * x.permute(0, 3, 2, 1).reshape(B, T, C * D) of the pooled map, frames[(b, w)][h * C + c], as bf16 (the MLP's GEMM operand) and / or
+ * fp32 (into the stacked output, row stride ld32); frames_to_nhwc is its adjoint, summing two gradient sources.  meanmax_time:
+ * mean_max_pooling over the time axis of [B][T][D], arg = position of the maximum. */
+int sa_relu_mask_fwd(const float* x, int64_t ldx, int64_t M, int32_t C, const uint8_t* keep, float scale, void* y_bf16, int64_t ldy16, float* y_f32,
+                     int64_t ldy32, void* stream);
+int sa_relu_mask_bwd(const float* dy, int64_t lddy, const float* x_pre, int64_t ldx, int64_t M, int32_t C, const uint8_t* keep, float scale, void* dx_bf16,
+                     int64_t lddx, void* stream);
+int sa_nhwc_to_frames(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, void* frames_bf16, float* frames_f32, int64_t ld32, void* stream);
+int sa_frames_to_nhwc(const float* da, int64_t lda, const float* db, int64_t ldb, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
+int sa_meanmax_time_fwd(const float* x, int32_t B, int32_t T, int32_t D, float* out, int32_t* arg, void* stream);
+int sa_meanmax_time_bwd(const float* dout, const int32_t* arg, int32_t B, int32_t T, int32_t D, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,12 @@ _SIGNATURES = {
     "sa_bn_bwd_stats_tall": [P, I32, I64, P, I64, I64, I32, P, P, P, P, I32, P, P, P, P],
     "sa_maxpool2_fwd": [P, I32, I32, I32, I32, P, P, P],
     "sa_maxpool2_bwd": [P, P, I32, I32, I32, I32, P, P],
+    "sa_relu_mask_fwd": [P, I64, I64, I32, P, F32, P, I64, P, I64, P],
+    "sa_relu_mask_bwd": [P, I64, P, I64, I64, I32, P, F32, P, I64, P],
+    "sa_nhwc_to_frames": [P, I32, I32, I32, I32, P, P, I64, P],
+    "sa_frames_to_nhwc": [P, I64, P, I64, I32, I32, I32, I32, P, P],
+    "sa_meanmax_time_fwd": [P, I32, I32, I32, P, P, P],
+    "sa_meanmax_time_bwd": [P, P, I32, I32, I32, P, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -296,6 +296,116 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- AudioNTT glue (model.py:153-191)
+// y = relu(x) [* keep * scale]  (nn.ReLU, then nn.Dropout in train mode with the caller's keep mask), x fp32 [M][C] with row stride ldx
+__global__ __launch_bounds__(256) void relu_mask_fwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, const uint8_t* __restrict__ keep,
+                                                            float scale, bf16_t* __restrict__ y16, int64_t ldy16, float* __restrict__ y32, int64_t ldy32) {
+  const int c4 = C >> 2;
+  const int64_t total = M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int64_t m = i / c4;
+    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + cc * 4);
+    float o[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    if (keep) {
+      const uint32_t k4 = *reinterpret_cast<const uint32_t*>(keep + m * C + cc * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = ((k4 >> (8 * r)) & 0xFF) ? o[r] * scale : 0.f;
+    }
+    if (y16) *reinterpret_cast<bf16x4*>(y16 + m * ldy16 + cc * 4) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+    if (y32) *reinterpret_cast<float4*>(y32 + m * ldy32 + cc * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dx = dy * [x_pre > 0] [* keep * scale] -> bf16 (the operand of the layer's dgrad / wgrad GEMMs)
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ xpre, int64_t ldx, int64_t M,
+                                                            int C, const uint8_t* __restrict__ keep, float scale, bf16_t* __restrict__ dx16, int64_t lddx) {
+  const int c4 = C >> 2;
+  const int64_t total = M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int64_t m = i / c4;
+    const float4 g = *reinterpret_cast<const float4*>(dy + m * lddy + cc * 4);
+    const float4 v = *reinterpret_cast<const float4*>(xpre + m * ldx + cc * 4);
+    float o[4] = {v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f};
+    if (keep) {
+      const uint32_t k4 = *reinterpret_cast<const uint32_t*>(keep + m * C + cc * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = ((k4 >> (8 * r)) & 0xFF) ? o[r] * scale : 0.f;
+    }
+    *reinterpret_cast<bf16x4*>(dx16 + m * lddx + cc * 4) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+  }
+}
+
+// x bf16 NHWC [B][H][W][C] -> frames[(b, w)][h * C + c]  (x.permute(0, 3, 2, 1).reshape(B, T, C * D), model.py:161-163): bf16 and / or fp32
+__global__ __launch_bounds__(256) void nhwc_to_frames_kernel(const bf16_t* __restrict__ x, int B, int H, int W, int C, bf16_t* __restrict__ f16,
+                                                             float* __restrict__ f32, int64_t ld32) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)B * H * W * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    const int64_t r = i / c8;
+    const int h = (int)(r % H), w = (int)((r / H) % W), b = (int)(r / ((int64_t)H * W));      // output-major: consecutive threads write one frame row
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + h) * W + w) * C + cc * 8);
+    const int64_t row = (int64_t)b * W + w;
+    if (f16) *reinterpret_cast<bf16x8*>(f16 + row * ((int64_t)H * C) + h * C + cc * 8) = v;
+    if (f32) {
+      float* o = f32 + row * ld32 + h * C + cc * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]));
+      *reinterpret_cast<float4*>(o + 4) = make_float4(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]));
+    }
+  }
+}
+
+// dx[b][h][w][c] = da[(b, w)][h * C + c] + db[(b, w)][h * C + c]   (either source may be null)
+__global__ __launch_bounds__(256) void frames_to_nhwc_kernel(const float* __restrict__ da, int64_t lda, const float* __restrict__ db, int64_t ldb, int B,
+                                                             int H, int W, int C, float* __restrict__ dx) {
+  const int c4 = C >> 2;
+  const int64_t total = (int64_t)B * H * W * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int64_t pix = i / c4;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    const int64_t row = (int64_t)b * W + w;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (da) v = *reinterpret_cast<const float4*>(da + row * lda + h * C + cc * 4);
+    if (db) {
+      const float4 u = *reinterpret_cast<const float4*>(db + row * ldb + h * C + cc * 4);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(dx + pix * C + cc * 4) = v;
+  }
+}
+
+// mean_max_pooling (model.py:185-190): out[b][f] = max_t x[b][t][f] + mean_t x[b][t][f]; arg = first t of the maximum
+__global__ __launch_bounds__(256) void meanmax_fwd_kernel(const float* __restrict__ x, int B, int T, int D, float* __restrict__ out, int32_t* __restrict__ arg) {
+  const int64_t total = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % D), b = (int)(i / D);
+    const float* p = x + (int64_t)b * T * D + f;
+    float mx = p[0], sum = 0.f;
+    int am = 0;
+    for (int t = 0; t < T; ++t) {
+      const float v = p[(int64_t)t * D];
+      sum += v;
+      if (v > mx) { mx = v; am = t; }
+    }
+    out[i] = mx + sum / (float)T;
+    arg[i] = am;
+  }
+}
+
+__global__ __launch_bounds__(256) void meanmax_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int B, int T, int D,
+                                                          float* __restrict__ dx) {
+  const int64_t total = (int64_t)B * T * D;
+  const float invT = 1.f / (float)T;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % D), t = (int)((i / D) % T), b = (int)(i / ((int64_t)D * T));
+    const float g = dout[(int64_t)b * D + f];
+    dx[i] = g * (invT + (arg[(int64_t)b * D + f] == t ? 1.f : 0.f));
+  }
+}
+
 }  // namespace
 
 static inline int conv_out(int n, int s) { return (n + 2 - 3) / s + 1; }
@@ -393,5 +503,58 @@ extern "C" int sa_maxpool2_bwd(const float* dy, const uint8_t* idx, int32_t B, i
   SA_CHECK_ARG(dy && idx && dx && B > 0 && H >= 2 && W >= 2 && C >= 8 && C % 8 == 0, "sa_maxpool2_bwd: bad args");
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, idx, B, H, W, C, dx);
   SA_LAUNCH_CHECK("sa_maxpool2_bwd");
+  return 0;
+}
+
+extern "C" int sa_relu_mask_fwd(const float* x, int64_t ldx, int64_t M, int32_t C, const uint8_t* keep, float scale, void* y_bf16, int64_t ldy16,
+                                float* y_f32, int64_t ldy32, void* stream) {
+  SA_CHECK_ARG(x && (y_bf16 || y_f32) && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && (!y_bf16 || ldy16 % 4 == 0) && (!y_f32 || ldy32 % 4 == 0),
+               "sa_relu_mask_fwd: bad args (C and the leading dimensions must be multiples of 4)");
+  hipLaunchKernelGGL(relu_mask_fwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, keep, scale, (bf16_t*)y_bf16, ldy16,
+                     y_f32, ldy32);
+  SA_LAUNCH_CHECK("sa_relu_mask_fwd");
+  return 0;
+}
+
+extern "C" int sa_relu_mask_bwd(const float* dy, int64_t lddy, const float* x_pre, int64_t ldx, int64_t M, int32_t C, const uint8_t* keep, float scale,
+                                void* dx_bf16, int64_t lddx, void* stream) {
+  SA_CHECK_ARG(dy && x_pre && dx_bf16 && M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0, "sa_relu_mask_bwd: bad args");
+  hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, lddy, x_pre, ldx, M, C, keep, scale,
+                     (bf16_t*)dx_bf16, lddx);
+  SA_LAUNCH_CHECK("sa_relu_mask_bwd");
+  return 0;
+}
+
+extern "C" int sa_nhwc_to_frames(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, void* frames_bf16, float* frames_f32, int64_t ld32,
+                                 void* stream) {
+  SA_CHECK_ARG(x_bf16 && (frames_bf16 || frames_f32) && B > 0 && H > 0 && W > 0 && C >= 8 && C % 8 == 0 && (!frames_f32 || ld32 % 4 == 0),
+               "sa_nhwc_to_frames: bad args");
+  hipLaunchKernelGGL(nhwc_to_frames_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, B, H, W,
+                     C, (bf16_t*)frames_bf16, frames_f32, ld32);
+  SA_LAUNCH_CHECK("sa_nhwc_to_frames");
+  return 0;
+}
+
+extern "C" int sa_frames_to_nhwc(const float* da, int64_t lda, const float* db, int64_t ldb, int32_t B, int32_t H, int32_t W, int32_t C, float* dx,
+                                 void* stream) {
+  SA_CHECK_ARG((da || db) && dx && B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && (!da || lda % 4 == 0) && (!db || ldb % 4 == 0),
+               "sa_frames_to_nhwc: bad args");
+  hipLaunchKernelGGL(frames_to_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, lda, db, ldb, B, H, W, C,
+                     dx);
+  SA_LAUNCH_CHECK("sa_frames_to_nhwc");
+  return 0;
+}
+
+extern "C" int sa_meanmax_time_fwd(const float* x, int32_t B, int32_t T, int32_t D, float* out, int32_t* arg, void* stream) {
+  SA_CHECK_ARG(x && out && arg && B > 0 && T > 0 && D > 0, "sa_meanmax_time_fwd: bad args");
+  hipLaunchKernelGGL(meanmax_fwd_kernel, dim3(grid_for((int64_t)B * D)), dim3(256), 0, (hipStream_t)stream, x, B, T, D, out, arg);
+  SA_LAUNCH_CHECK("sa_meanmax_time_fwd");
+  return 0;
+}
+
+extern "C" int sa_meanmax_time_bwd(const float* dout, const int32_t* arg, int32_t B, int32_t T, int32_t D, float* dx, void* stream) {
+  SA_CHECK_ARG(dout && arg && dx && B > 0 && T > 0 && D > 0, "sa_meanmax_time_bwd: bad args");
+  hipLaunchKernelGGL(meanmax_bwd_kernel, dim3(grid_for((int64_t)B * T * D)), dim3(256), 0, (hipStream_t)stream, dout, arg, B, T, D, dx);
+  SA_LAUNCH_CHECK("sa_meanmax_time_bwd");
   return 0;
 }

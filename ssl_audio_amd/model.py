@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import mae
+from .audiontt import AudioNTT2022, AudioNTT2022Encoder  # noqa: F401  (model.py:130-177 of the reference defines them here)
 
 
 def _chunked_mlp(x, ncrops, seq):
@@ -63,7 +64,10 @@ class ModelWrapper(nn.Module):
         self._setup_model()
 
     def _setup_model(self):
-        if 'vit' in self.cfg.model_type:
+        if self.cfg.model_type == 'audiontt':
+            assert self.cfg.n_mels == 64, f'n_mels must be 64 to use AudioNTT encoder (n_mels set to {self.cfg.n_mels})'
+            self.encoder = AudioNTT2022(squeeze_excitation=self.cfg.squeeze_excitation)
+        elif 'vit' in self.cfg.model_type:
             conv_stem_bool = self.cfg.model_type.split('_')[0] == 'vitc'
             self.encoder = ViT(
                 dataset=self.cfg.dataset,
@@ -78,12 +82,14 @@ class ModelWrapper(nn.Module):
                 img_size=(self.cfg.n_mels, self.cfg.crop_frames) if (self.cfg.masked_recon and self.cfg.crop_frames % 16 == 0) else None,
             )
         else:
-            # resnet* / audiontt encoders run on stock ops in the reference and are not part of this hot path
+            # resnet* encoders run on stock ops in the reference (BASELINE config 1: CPU plumbing) and are not part of this hot path
             raise NotImplementedError(f'Model type {self.cfg.model_type} is not supported on the MI355X hot path')
         self.feature_dim = self.encoder.embed_dim
 
     def forward(self, x, mask_ratio=0, masked_recon=False):
-        return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon)
+        if 'vit' in self.cfg.model_type:
+            return self.encoder(x, mask_ratio=mask_ratio, masked_recon=masked_recon)
+        return self.encoder(x)
 
 
 class ViT(nn.Module):

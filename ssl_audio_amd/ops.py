@@ -433,6 +433,38 @@ def maxpool2_bwd(dy, idx, B, H, W, C, dx):
     check(lib().sa_maxpool2_bwd(_p(_req(dy, F32, "dy")), _p(idx), B, H, W, C, _p(_req(dx, F32, "dx")), _stream()), "sa_maxpool2_bwd")
 
 
+def relu_mask_fwd(x, keep, scale, *, y_bf16=None, y_f32=None):
+    M, Cn, ld = _rows(_req(x, F32, "x"), "x")
+    check(lib().sa_relu_mask_fwd(_p(x), ld, M, Cn, _p(keep), float(scale), _p(y_bf16), _rows(y_bf16, "y")[2] if y_bf16 is not None else 0,
+                                 _p(y_f32), _rows(y_f32, "y")[2] if y_f32 is not None else 0, _stream()), "sa_relu_mask_fwd")
+
+
+def relu_mask_bwd(dy, x_pre, keep, scale, dx_bf16):
+    M, Cn, ld = _rows(_req(x_pre, F32, "x_pre"), "x_pre")
+    check(lib().sa_relu_mask_bwd(_p(_req(dy, F32, "dy")), _rows(dy, "dy")[2], _p(x_pre), ld, M, Cn, _p(keep), float(scale), _p(_req(dx_bf16, BF16, "dx")),
+                                 _rows(dx_bf16, "dx")[2], _stream()), "sa_relu_mask_bwd")
+
+
+def nhwc_to_frames(x16, B, H, W, C, frames_bf16=None, frames_f32=None):
+    check(lib().sa_nhwc_to_frames(_p(_req(x16, BF16, "x")), B, H, W, C, _p(frames_bf16), _p(frames_f32),
+                                  _rows(frames_f32, "frames_f32")[2] if frames_f32 is not None else 0, _stream()), "sa_nhwc_to_frames")
+
+
+def frames_to_nhwc(da, db, B, H, W, C, dx):
+    check(lib().sa_frames_to_nhwc(_p(da), _rows(da, "da")[2] if da is not None else 0, _p(db), _rows(db, "db")[2] if db is not None else 0, B, H, W, C,
+                                  _p(_req(dx, F32, "dx")), _stream()), "sa_frames_to_nhwc")
+
+
+def meanmax_time_fwd(x, out, arg):
+    B, T_, D = x.shape
+    check(lib().sa_meanmax_time_fwd(_p(_req(x, F32, "x")), B, T_, D, _p(_req(out, F32, "out")), _p(arg), _stream()), "sa_meanmax_time_fwd")
+
+
+def meanmax_time_bwd(dout, arg, dx):
+    B, T_, D = dx.shape
+    check(lib().sa_meanmax_time_bwd(_p(_req(dout, F32, "dout")), _p(arg), B, T_, D, _p(_req(dx, F32, "dx")), _stream()), "sa_meanmax_time_bwd")
+
+
 def device_info():
     name = C.create_string_buffer(128)
     cus = C.c_int32(0)

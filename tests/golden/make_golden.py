@@ -575,8 +575,37 @@ def gen_convstem():
     save("convstem", **out)
 
 
+def gen_audiontt():
+    """AudioNTT2022 (model.py:130-191) in train mode: BatchNorm2d on batch statistics, Dropout(0.3) with its mask recovered from a
+    forward hook (input / output of the Dropout module), small MLP widths so the fixture stays small (n_mels 64, d 1280, hidden 256)."""
+    out = {}
+    torch.manual_seed(0)
+    m = ref_model.AudioNTT2022(n_mels=64, d=1280, mlp_hidden_d=256)
+    m.train()
+    for k, v in m.state_dict().items():
+        out["sd." + k] = t2n(v)
+    rec = {}
+    hook = m.fc[2].register_forward_hook(lambda mod, inp, o: rec.update(inp=inp[0].detach().clone(), out=o.detach().clone()))
+    torch.manual_seed(5)
+    x = torch.randn(3, 1, 64, 40)
+    y = m(x)
+    hook.remove()
+    keep = ((rec["out"] != 0) | (rec["inp"] == 0)).float()        # where the input is 0 the draw is unobservable (and irrelevant)
+    w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    m.zero_grad()
+    (y * w).sum().backward()
+    out.update(x=t2n(x), y=t2n(y), keep=t2n(keep))
+    for n, prm in m.named_parameters():
+        out["grad." + n] = t2n(prm.grad)
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out["after." + k] = t2n(v)
+    save("audiontt", **out)
+
+
 if __name__ == "__main__":
     gen_convstem() if "convstem" in sys.argv[1:] else None
+    gen_audiontt() if "audiontt" in sys.argv[1:] else None
     if len(sys.argv) > 1:
         sys.exit(0)
     gen_bt_loss()

@@ -172,3 +172,67 @@ def test_vitc_base_16x8_10s_runs(dev):
     bad = [k for k, p in m.named_parameters() if p.requires_grad and (p.grad is None or not torch.isfinite(p.grad).all() or float(p.grad.abs().max()) == 0.0)]
     assert not bad, bad[:5]
     assert len(m.blocks) == 11 and m.patch_embed.num_patches == 4 * 12
+
+
+# ------------------------------------------------------------------------------------------------ AudioNTT (model.py:130-191)
+def test_audiontt_golden(dev, golden):
+    """AudioNTT2022 with the reference's weights, train mode (BatchNorm2d batch statistics, the reference run's Dropout mask): output
+    rel 1e-2, gradients rel 3e-2 of the reference's fp32 values (the two conv biases sit ahead of a BatchNorm: true gradient 0, skipped),
+    running statistics; then the AudioNTT glue kernels against torch."""
+    from ssl_audio_amd.audiontt import AudioNTT2022
+    g = golden("audiontt")
+    m = AudioNTT2022(n_mels=64, d=1280, mlp_hidden_d=256).to(dev)
+    sd = {k[3:]: T(v, dev, torch.long if "num_batches" in k else torch.float32) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    x = T(g["x"], dev)
+    keep = T(g["keep"], dev).reshape(-1, 256).to(torch.uint8).contiguous()
+    y = m(x, keep=keep)
+    assert y.shape == (3, 1280) and rel(y, g["y"]) < 1e-2, rel(y, g["y"])
+    w = torch.linspace(-1, 1, y.numel(), device=dev).reshape(y.shape)
+    (y * w).sum().backward()
+    errs = {n: rel(p.grad, g["grad." + n]) for n, p in m.named_parameters() if float(np.linalg.norm(g["grad." + n])) > 1e-2}
+    print("audiontt gradient rel errors vs the reference:", {k: round(v, 4) for k, v in errs.items()})
+    # from the second BatchNorm's own affine parameters on the gradients are well conditioned: 3e-2 of the reference's values.  Behind a
+    # BatchNorm backward (features.0 / .1 / .4) they are bf16-sensitive like the ConvStem's lower stages: bounded by 3 x the measured
+    # mirror-vs-fp32 sensitivity (tests/gradcheck.py)
+    tight = {k: v for k, v in errs.items() if k.startswith(("fc.", "features.5"))}
+    assert len(errs) == 10 and len(tight) == 6 and max(tight.values()) < 3e-2, errs
+    from gradcheck import check_step_gradients
+    from oracle import audiontt as oa, rounding as R
+    cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    names = [n for n, _ in m.named_parameters()]
+
+    def oracle_grads(mirror):
+        leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in cpu.items()}
+        with R.mirror_hip_bf16(mirror):
+            ref = oa.forward(x.cpu(), leaf, T(g["keep"]))
+            gs = torch.autograd.grad((ref * w.cpu()).sum(), [leaf[k] for k in names])
+        return {k: gr for k, gr in zip(names, gs) if float(np.linalg.norm(g["grad." + k])) > 1e-2}
+
+    check_step_gradients("audiontt", {n: p.grad for n, p in m.named_parameters()}, oracle_grads(True), oracle_grads(False), 10)
+    after = m.state_dict()
+    for k in [k for k in g if k.startswith("after.")]:
+        if "num_batches" in k:
+            assert int(after[k[6:]]) == int(g[k])
+        else:
+            np.testing.assert_allclose(after[k[6:]].cpu().numpy(), g[k], rtol=1e-2, atol=1e-3, err_msg=k)
+    m.eval()                                             # eval: running statistics, no dropout; runs and is deterministic
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x))
+
+
+def test_audiontt_default_size_through_model_wrapper(dev):
+    """`--model_type audiontt` (the reference's default) behind ModelWrapper + BarlowTwinsHead: d = 3072, forward + backward at B = 8."""
+    from ssl_audio_amd import hyperparameters as hp, model, utils
+    cfg = hp.make_args(model_type="audiontt", batch_size=8)
+    torch.manual_seed(0)
+    net = utils.MultiCropWrapper(model.ModelWrapper(cfg), model.BarlowTwinsHead(cfg, 3072)).to(dev)
+    assert net.backbone.feature_dim == 3072
+    g = torch.Generator().manual_seed(1)
+    views = [torch.randn(8, 1, 64, 96, generator=g).to(dev), torch.randn(8, 1, 64, 96, generator=g).to(dev)]
+    z = net(views, ncrops=2)
+    assert z.shape == (16, 256) and torch.isfinite(z).all()
+    z.square().mean().backward()
+    bad = [k for k, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not bad, bad

@@ -380,3 +380,25 @@ def test_hear_frame_audio_matches_the_reference_loop():
         fr, ts = hutils.frame_audio(a, frame, hop, 16000)
         rf, rt = ohear.frame_audio(a.numpy(), frame, hop, 16000)
         assert fr.shape == rf.shape and np.array_equal(fr.numpy(), rf) and np.allclose(ts.numpy(), rt)
+
+
+def test_audiontt_oracle_golden(golden):
+    """oracle.audiontt (model.py:130-191) against the reference's AudioNTT2022 run in train mode with its own Dropout mask: output 1e-5,
+    gradients 1e-5 (the conv biases sit ahead of a BatchNorm: true gradient 0, rounding noise only -- skipped)."""
+    from oracle import audiontt as oa
+    g = golden("audiontt")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    names = [k for k in sd if not ("running" in k or "num_batches" in k)]
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    st = []
+    y = oa.forward(torch.from_numpy(g["x"]), leaf, torch.from_numpy(g["keep"]), bn_stats=st)
+    assert float((y.detach() - torch.from_numpy(g["y"])).abs().max()) < 1e-5
+    w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    gs = dict(zip(names, torch.autograd.grad((y * w).sum(), [leaf[k] for k in names])))
+    for k, v in g.items():
+        if k.startswith("grad.") and float(np.linalg.norm(v)) > 1e-2:
+            ref = torch.from_numpy(v)
+            assert float((gs[k[5:]] - ref).norm() / ref.norm()) < 1e-5, k
+    for l, (mu, var, n) in enumerate(st):
+        rv = 0.9 * sd[f"features.{4 * l + 1}.running_var"] + 0.1 * var * n / (n - 1)
+        np.testing.assert_allclose(rv.numpy(), g[f"after.features.{4 * l + 1}.running_var"], rtol=1e-4, atol=1e-6)
