@@ -30,6 +30,31 @@ GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol
                # config 5 as main.py runs it: view 1 masked (63 tokens) + decoder, view 2 UNMASKED ViT-L: 3 * (156.6 + 38.6 + 4.0) GF
                "vit_large_mae_10s": 597.6}
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy)
+
+
+def source_sha():
+    """Hash of the kernel sources: profiles/r02_gemm_traffic.json carries the hash it was collected at and is ignored when stale."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def executed_gflop_per_clip(model_type, mode, N):
+    """Matmul FLOPs the step really EXECUTES per clip (2 views, forward + backward = 3 x forward).  Differs from the algorithmic
+    GF_PER_CLIP (what `value`'s metric is priced in) where the engine skips work exactly: with CLS pooling the last
+    block runs proj / MLP (and the attention queries) for the CLS row only (engine.block_forward_cls)."""
+    size = model_type.split("_")[-1]
+    d, L, H = {"tiny": (192, 12, 3), "small": (384, 12, 6), "base": (768, 12, 12), "large": (1024, 24, 16)}[size]
+    if mode == "mae":
+        return None                                  # masked + decoder passes: reported from the algorithmic figure only
+    full = 24.0 * N * d * d + 4.0 * N * N * d        # one block, all rows: qkv 6, proj 2, fc1 8, fc2 8 (x N d^2) + attention
+    pruned = 6.0 * N * d * d + 18.0 * d * d + 4.0 * N * d        # last block: qkv for all rows, the rest for the CLS row only
+    view = (L - 1) * full + pruned + 2.0 * (N - 1) * 256 * d + 2.0 * (d * 8192 + 8192 * 256)
+    passes = 8.0 if mode == "byol" else 6.0          # byol: online fwd+bwd (3) x 2 views + target fwd x 2 views
+    return view * passes / 1e9
 
 
 def cpu_baseline(workload, budget_clips=8, steps=16):
@@ -165,12 +190,14 @@ def main():
         note(f"warm-up step {i} done (loss {float(trainer.last_loss):.4f})")
     barrier()
     ops.GEMM_PROFILE = []                                          # HIP events around every GEMM launch of the timed region
+    ops.STREAM_PROFILE = {}                                        # ... and around the HBM-bound frontend / augmentation launches
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.step(pool[i % 2])
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    sprof, ops.STREAM_PROFILE = ops.STREAM_PROFILE, None
     trainer.assert_finite()                                        # the step's device-side finite-loss counter, read once here
     note(f"timed region done: {args.steps} steps in {dt:.3f}s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -196,12 +223,28 @@ def main():
         dom = max(by_kernel, key=lambda k: by_kernel[k][0])
         d_ms, d_fl, d_nb, d_n = by_kernel[dom]
         d_tflops = d_fl / (d_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        traffic, traffic_note = None, "no PMC summary for this workload"
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
         if os.path.exists(tpath) and args.workload == "vit_base_bt_10s" and B == 128:
-            # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/collect_traffic.sh)
+            # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/collect_traffic.sh), valid
+            # only for the kernel sources it was collected with
             tj = json.load(open(tpath))
-            traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch", tj.get("hbm_bytes_per_launch"))
+            if tj.get("source_sha") == source_sha():
+                traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE) of this command, profiles/r02_gemm_traffic.json"
+            else:
+                traffic_note = "profiles/r02_gemm_traffic.json is stale (kernel sources changed since it was collected): ignored"
+        n_tok = (64 // 16) * (frames // 16) + 1
+        exec_gf = executed_gflop_per_clip(model_type, mode, n_tok)
+        hbm_kernels = {}
+        for kname, recs in (sprof or {}).items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            nb = sum(b for _, _, b in recs)
+            if ms > 0:
+                gbs = nb / (ms * 1e-3) / 1e9
+                hbm_kernels[kname] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                      "launches": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
+                                      "algorithmic_bytes_per_launch": round(nb / len(recs)), "share_of_step": round(ms / (dt * 1e3), 4)}
         line = {
             "metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,7 +256,7 @@ def main():
                        "loss": round(loss_val, 4)},
             "roofline": {"bound": "mfma", "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
                          "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                         "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_note": traffic_note,
                          "algorithmic_flop_per_launch": round(d_fl / d_n), "algorithmic_bytes_per_launch": round(d_nb / d_n),
                          "launches": d_n, "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
                          "share_of_step": round(d_ms / (dt * 1e3), 4),
@@ -222,7 +265,10 @@ def main():
                                       "by_kernel": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[3],
                                                         "avg_launch_us": round(v[0] * 1e3 / v[3], 2)} for k, v in by_kernel.items() if v[0] > 0},
                                       "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0}},
-                         "whole_step_tflops": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2)},
+                         "hbm_kernels": hbm_kernels,
+                         "whole_step_tflops_algorithmic": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2),
+                         "executed_gflop_per_clip": round(exec_gf, 1) if exec_gf else None,
+                         "whole_step_tflops": round(clips_per_s / world * (exec_gf or GF_PER_CLIP[args.workload]) / 1e3, 2)},
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only (rank 0 is the only rank)
             note("timing the CPU baseline (oracle on host cores) ...")

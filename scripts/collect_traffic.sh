@@ -4,6 +4,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/traffic
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic/$c -- python bench.py --steps 2 --warmup 1 --no_cpu_baseline > gpurun_out/traffic_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/traffic/$c -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline > gpurun_out/traffic_$c.log 2>&1
 done
-python scripts/traffic_summary.py gpurun_out/traffic gpurun_out/r01_gemm_traffic.json   # copy to profiles/ after the run (only gpurun_out/ is merged back)
+python scripts/traffic_summary.py gpurun_out/traffic gpurun_out/r02_gemm_traffic.json   # copy to profiles/ after the run (only gpurun_out/ is merged back)

@@ -7,6 +7,7 @@ root, out = sys.argv[1], sys.argv[2]
 def family(name):
     if "colsum" in name or "gemm" not in name:
         return None
+    if "gemm256_phase_kernel" in name: return "gemm256_phase_kernel"
     if "gemm256_persist_kernel" in name: return "gemm256_persist_kernel"
     if "gemm256_ring_kernel" in name: return "gemm256_ring_kernel<split-K>" if "true>(" in name.split("gemm256_ring_kernel")[1][:24].replace(" ", "").split(",")[-1] else "gemm256_ring_kernel"
     if "gemm256_kernel" in name: return "gemm256_kernel<split-K>"
@@ -35,6 +36,9 @@ def summarise(d):
 
 res = summarise(tot["__all__"])
 res["per_kernel"] = {k: summarise(v) for k, v in tot.items() if k != "__all__"}
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench
+res["source_sha"] = bench.source_sha()          # bench.py ignores this file once the kernel sources differ
 res["note"] = "sa_gemm_bf16 launches of `bench.py --steps 2 --warmup 1` (3 steps); FETCH_SIZE doubled per the gfx950 correction"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: (v if k != "per_kernel" else {n: round(x["hbm_bytes_per_launch"] / 1e6, 1) for n, x in v.items()}) for k, v in res.items()}))

@@ -13,6 +13,19 @@ from ._lib import SaGemmArgs, check, lib
 BF16 = torch.bfloat16
 F32 = torch.float32
 GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end event, flops, layout) per GEMM launch
+STREAM_PROFILE = None  # set to a dict by bench.py: kernel name -> [(start event, end event, algorithmic bytes)] for the HBM-bound front kernels
+
+
+def _timed(name, nbytes, launch):
+    """bench.py's roofline leg for the HBM-bound kernels: HIP events on the launch stream around one launch."""
+    if STREAM_PROFILE is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    STREAM_PROFILE.setdefault(name, []).append((e0, e1, float(nbytes)))
 
 
 def _stream():
@@ -79,7 +92,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     check(lib().sa_gemm_bf16(C.byref(a), _stream()), "sa_gemm_bf16")
     e1.record()
     kind = ("NT" if b_kmajor else "NN") if a_kmajor else ("TT" if b_kmajor else "TN")
-    kname = gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256)
+    epi3 = (residual is not None and not res_mod and not row_group and out_f32 is not None and out_bf16 is None and act == 0 and aux_in is None
+            and aux_out is None and colsum_out is None and not accumulate and N % 64 == 0)
+    kname = gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3)
     nbytes = 2.0 * (M * K + N * K) + (4.0 * M * N if out_f32 is not None else 0.0) + (2.0 * M * N if out_bf16 is not None else 0.0) \
         + (2.0 * M * N if (aux_in is not None or aux_out is not None) else 0.0) + (4.0 * M * N if residual is not None and not res_mod else 0.0)
     GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes, kname))
@@ -109,15 +124,18 @@ def set_cu_budget(cus):
     CU_BUDGET = int(cus) if cus else None
 
 
-def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256):
+def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
-    override); used to label bench.py's per-launch timings with the names rocprofv3 reports."""
+    override); used to label bench.py's per-launch timings with the names rocprofv3 reports.  epi3: the launch has the compact
+    bias + residual -> fp32 epilogue (proj / fc2 forward), which the forward layout runs on the phased kernel."""
     if split_k > 1:
         return "gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>"
     big = M >= 1024 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
     if not big:
         return "gemm_kernel"
-    return "gemm256_ring_kernel" if (a_kmajor and not b_kmajor) else "gemm256_persist_kernel"
+    if a_kmajor and not b_kmajor:
+        return "gemm256_ring_kernel"
+    return "gemm256_phase_kernel" if (a_kmajor and b_kmajor and epi3 and K >= 128) else "gemm256_persist_kernel"
 
 
 def pick_split_k(M, N, K, cu_count=None, tile=128):
@@ -282,16 +300,20 @@ def count_nonfinite(x, flag):
 # ------------------------------------------------------------------------------------------------ frontend / augmentation
 def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop):
     B, L = wave.shape
-    check(lib().sa_logmel_fwd(_p(_req(wave, F32, "wave")), wave.stride(0), B, L, _p(tables["window"]), _p(tables["twiddle"]),
-                              _p(tables["mel_weights"]), _p(tables["mel_lo"]), _p(tables["mel_len"]), _p(_req(out, F32, "out")),
-                              out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd")
+    # algorithmic bytes: the waveform read once + the log-mel written once
+    _timed("logmel_kernel", 4.0 * B * L + 4.0 * B * 64 * T_out, lambda: check(
+        lib().sa_logmel_fwd(_p(_req(wave, F32, "wave")), wave.stride(0), B, L, _p(tables["window"]), _p(tables["twiddle"]),
+                            _p(tables["mel_weights"]), _p(tables["mel_lo"]), _p(tables["mel_len"]), _p(_req(out, F32, "out")),
+                            out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd"))
 
 
 def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in, canvas, max_w_ratio, do_fade):
     V, F_out, T_out = out.shape[0], out.shape[-2], out.shape[-1]
-    check(lib().sa_augment_views(_p(_req(lms, F32, "lms")), clip_stride, _p(src_slot), _p(mix_slot), _p(_req(params, F32, "params")),
-                                 _p(_req(out, F32, "out")), V, F_in, T_in, canvas[0], canvas[1], F_out, T_out, float(max_w_ratio),
-                                 int(do_fade), _stream()), "sa_augment_views")
+    # algorithmic bytes per view: the clip and its mixup partner read once, the view written once
+    _timed("augment_kernel", V * 4.0 * (2 * F_in * T_in + F_out * T_out), lambda: check(
+        lib().sa_augment_views(_p(_req(lms, F32, "lms")), clip_stride, _p(src_slot), _p(mix_slot), _p(_req(params, F32, "params")),
+                               _p(_req(out, F32, "out")), V, F_in, T_in, canvas[0], canvas[1], F_out, T_out, float(max_w_ratio),
+                               int(do_fade), _stream()), "sa_augment_views"))
 
 
 def normalize_batch(x, y, shift, workspace, eps, stat_div=1.0):
