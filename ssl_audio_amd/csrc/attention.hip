@@ -74,6 +74,15 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 
 #define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
 
+// operand prescale: the backward folds scale * log2(e) into the register-resident Q (pass A) / K (pass B) fragment, so the scores
+// come out of the MFMA chain in log2 units and, with -lse as the chain's initial accumulator, p = exp2(acc) needs no further VALU
+__device__ __forceinline__ bf16x8 scale_frag(const bf16x8& x, float c) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f2bf(bf2f(x[j]) * c);
+  return r;
+}
+
 // =====================================================================================================
 template <int NMAX>
 __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
@@ -224,9 +233,9 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);
       if (ch == 0) {
-        del_s[q] = q < nq ? dl : 0.f;
-        // queries >= nq: lse = +inf makes every p exactly 0; kept in log2 units for v_exp
-        lse_s[q] = q < nq ? ls[it] * 1.44269504088896340736f : INFINITY;
+        // both stored NEGATED: they are the initial accumulators of the S and dP chains.  queries >= nq: -lse = -inf makes every p exactly 0
+        del_s[q] = q < nq ? -dl : 0.f;
+        lse_s[q] = q < nq ? -ls[it] * 1.44269504088896340736f : -INFINITY;           // log2 units for v_exp
       }
     }
   }
@@ -252,7 +261,6 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     return __builtin_bit_cast(bf16x8, v);
   };
   const float c2 = scale * 1.44269504088896340736f;    // p = exp(scale*s - lse) = exp2(c2*s - lse*log2e)
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
   const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
@@ -267,9 +275,11 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
       }
       continue;
     }
-    const bf16x8 qf0 = row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), qf1 = row_frag_global(rs, ld, qt * 16, h * HD, 1, lane);
+    const bf16x8 qf0 = scale_frag(row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), c2), qf1 = scale_frag(row_frag_global(rs, ld, qt * 16, h * HD, 1, lane), c2);
     const bf16x8 df0 = row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), df1 = row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane);
-    const float lq = lse_s[query], dq_delta = del_s[query];
+    // initial accumulators of the two chains (loop invariant, the MFMA's C operand): S' = c2 s - lse, dP' = dP - delta
+    const float nl = lse_s[query], nd = del_s[query];      // -lse (log2 units), -delta
+    const f32x4 s_init = {nl, nl, nl, nl}, d_init = {nd, nd, nd, nd};
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -278,19 +288,19 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int kt = 2 * ps + u;
-        f32x4 sv = zero4, dp = zero4;
+        f32x4 sv = s_init, dp;
         if (kt >= nkt - 1) {                            // wave-uniform and rare: tiles holding keys >= N start at -inf
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : 0.f;
+          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : nl;
         }
         sv = MFMA16(RF(Kimg, kt, 0), qf0, sv);
         sv = MFMA16(RF(Kimg, kt, 1), qf1, sv);
-        dp = MFMA16(RF(Vimg, kt, 0), df0, dp);
+        dp = MFMA16(RF(Vimg, kt, 0), df0, d_init);
         dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq));   // 0 for padding keys (-inf) and un-queried rows (lq = +inf)
-          ds[u][r] = p * (dp[r] - dq_delta);                              // the softmax scale is applied once, to the accumulator
+          const float p = __builtin_amdgcn_exp2f(sv[r]);                  // 0 for padding keys (-inf) and un-queried rows (lse = +inf)
+          ds[u][r] = p * dp[r];                                           // the softmax scale is applied once, to the accumulator
         }
       }
       const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -317,8 +327,8 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
     const float kb = kvalid ? 0.f : -INFINITY;
-    const f32x4 kb4 = {kb, kb, kb, kb};
-    const bf16x8 kf0 = row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), kf1 = row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane);
+    const bool kvalid_wave = kt * 16 + 16 <= N;           // wave-uniform: every key of this tile is real
+    const bf16x8 kf0 = scale_frag(row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), c2), kf1 = scale_frag(row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane), c2);
     const bf16x8 vf0 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), vf1 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane);
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -328,19 +338,22 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qs + u;
-        f32x4 sv = kb4, dp = zero4;
+        // the chains start from -lse / -delta of this lane's 4 queries (stored negated in LDS: the loads ARE the C operands)
+        f32x4 sv = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+        f32x4 dp = *reinterpret_cast<const f32x4*>(del_s + qt * 16 + 4 * g);
+        if (!kvalid_wave) {                      // last key tile only: lanes whose key is padding start at -inf
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[r] += kb;
+        }
         sv = MFMA16(RF(Qimg, qt, 0), kf0, sv);   // D[query = 4g + r][key = c]
         sv = MFMA16(RF(Qimg, qt, 1), kf1, sv);
         dp = MFMA16(RF(Dimg, qt, 0), vf0, dp);
         dp = MFMA16(RF(Dimg, qt, 1), vf1, dp);
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + 4 * g);      // this lane's 4 queries
-        const float4 d4 = *reinterpret_cast<const float4*>(del_s + qt * 16 + 4 * g);
-        const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sv[r], c2, -lq4[r]));
+          const float p = __builtin_amdgcn_exp2f(sv[r]);
           pp[u][r] = p;
-          ds[u][r] = p * (dp[r] - dq4[r]);
+          ds[u][r] = p * dp[r];
         }
       }
       const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);

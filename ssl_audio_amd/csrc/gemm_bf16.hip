@@ -715,7 +715,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
         }
     } else {
       char* wl = smem + (wave < 4 ? ea * HALF + wave * 8192 : eb * HALF + (wave - 4) * 8192);
-      if constexpr (EPI != 0) {
+      if constexpr (EPI == 4 || EPI == 5) {
+        // the wave's whole aux_in block (128 rows x 64 columns) is requested before the first store: a load issued after a store
+        // sits behind it in the in-order vmcnt queue, and waiting for it would drain the first half's stores (an HBM round trip)
+        const int nb = n0 + wc * 64;
+        uint4 auxv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + wr * 128 + q * 8 + (lane >> 3);
+          auxv[q] = (m < p.M && nb < p.N) ? *reinterpret_cast<const uint4*>(p.aux_in + (int64_t)m * p.ldaux + nb + (lane & 7) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, nb, wl, lane, nullptr, nullptr, &auxv[0]);
+        wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, nb, wl, lane, nullptr, nullptr, &auxv[8]);
+      } else if constexpr (EPI != 0) {
         wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, n0 + wc * 64, wl, lane);
         wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, n0 + wc * 64, wl, lane);
       } else {
