@@ -4,7 +4,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm" not in k: continue
+        if not any(t in k for t in (sys.argv[2:] or ["gemm"])): continue
         agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)

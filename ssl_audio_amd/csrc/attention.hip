@@ -15,6 +15,7 @@
 // exact softmax keeps 512 scores per query in 128 registers).
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 #include "../../include/ssl_audio_hip.h"
 
 namespace {
@@ -71,6 +72,14 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   bf16x8 r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
   return r;
 }
+
+// two fp32 -> one dword of two bf16 (v_cvt_pk_bf16_f32); building fragments from explicit pairs keeps the compiler from pairing
+// neighbouring elements of different registers and re-aligning them with v_perm / v_alignbit afterwards
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
+__device__ __forceinline__ uint32_t cvt_pk(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
 
@@ -206,6 +215,19 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   const int nkt = (N + 15) >> 4;
   const int nks = (N + 31) >> 5;
   const int nrows = nks * 32;
+  // The operand a wave owns (Q, dO of its query tile in pass A; K, V of its key tile in pass B) comes straight from global as four
+  // 16-byte row fragments.  Each tile's fragments are requested one tile ahead -- the first ones here, ahead of the staging -- so
+  // that no tile starts with an exposed L2 / HBM round trip.
+  struct Frag4 { bf16x8 a0, a1, b0, b1; };
+  auto load_qd = [&](int qt) {
+    return Frag4{row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), row_frag_global(rs, ld, qt * 16, h * HD, 1, lane),
+                 row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane)};
+  };
+  auto load_kv = [&](int kt) {
+    return Frag4{row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane),
+                 row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane)};
+  };
+  Frag4 nxt = load_qd(wave);
   stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
   // delta[q] = sum_d dO[q][d] * O[q][d], lse -> LDS.  Eight lanes share a query row (8 x 16 B = the row's 128 bytes of one head), so
@@ -266,6 +288,8 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
   for (int qt = wave; qt < nkt; qt += NW_BWD) {
     const int query = qt * 16 + c;
+    const Frag4 cur = nxt;
+    if (qt + NW_BWD < nkt) nxt = load_qd(qt + NW_BWD);
     if (qt >= nqt) {                                       // dQ of an un-queried tile is exactly zero
       if (query < N) {
         bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
@@ -275,21 +299,23 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
       }
       continue;
     }
-    const bf16x8 qf0 = scale_frag(row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), c2), qf1 = scale_frag(row_frag_global(rs, ld, qt * 16, h * HD, 1, lane), c2);
-    const bf16x8 df0 = row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), df1 = row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane);
+    const bf16x8 qf0 = scale_frag(cur.a0, c2), qf1 = scale_frag(cur.a1, c2);
+    const bf16x8 df0 = cur.b0, df1 = cur.b1;
     // initial accumulators of the two chains (loop invariant, the MFMA's C operand): S' = c2 s - lse, dP' = dP - delta
     const float nl = lse_s[query], nd = del_s[query];      // -lse (log2 units), -delta
     const f32x4 s_init = {nl, nl, nl, nl}, d_init = {nd, nd, nd, nd};
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ps = 0; ps < nks; ++ps) {
-      f32x4 ds[2];
+    // one 32-key step.  Only the last step can hold keys >= N (they start at -inf so that p = 0); the others are unrolled with
+    // compile-time step numbers, so every LDS address is the lane's base register + an immediate.
+    auto step = [&](int ps, auto masked) {
+      u32x4 dsw;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int kt = 2 * ps + u;
         f32x4 sv = s_init, dp;
-        if (kt >= nkt - 1) {                            // wave-uniform and rare: tiles holding keys >= N start at -inf
+        if constexpr (decltype(masked)::value) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : nl;
         }
@@ -297,16 +323,21 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
         sv = MFMA16(RF(Kimg, kt, 1), qf1, sv);
         dp = MFMA16(RF(Vimg, kt, 0), df0, d_init);
         dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(sv[r]);                  // 0 for padding keys (-inf) and un-queried rows (lse = +inf)
-          ds[u][r] = p * dp[r];                                           // the softmax scale is applied once, to the accumulator
-        }
+        // p = exp2(S'): 0 for padding keys (-inf) and un-queried rows (-lse = -inf); dS = p * dP'; the softmax scale is applied once, to the accumulator
+        const f32x2 p01 = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])}, p23 = {__builtin_amdgcn_exp2f(sv[2]), __builtin_amdgcn_exp2f(sv[3])};
+        dsw[2 * u] = cvt_pk(p01 * f32x2{dp[0], dp[1]});
+        dsw[2 * u + 1] = cvt_pk(p23 * f32x2{dp[2], dp[3]});
       }
-      const bf16x8 dsf = pack8(ds[0], ds[1]);
+      const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(TR(Kimg, ps, dt), dsf, acc[dt]);
+    };
+#pragma unroll
+    for (int ps = 0; ps < NMAX / 32 - 1; ++ps) {
+      if (ps >= nks - 1) continue;
+      step(ps, std::false_type{});
     }
+    step(nks - 1, std::true_type{});
     if (query < N) {
       bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
 #pragma unroll
@@ -318,6 +349,7 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   }
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
+  nxt = load_kv(wave);
   __syncthreads();                                   // every wave is done reading the K / V images
   stage_rows(rs, Qimg, ld, h * HD, nqs * 32, wave, lane, NW_BWD);
   stage_rows(rd, Dimg, ldo, h * HD, nqs * 32, wave, lane, NW_BWD);
@@ -326,37 +358,35 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   for (int kt = wave; kt < nkt; kt += NW_BWD) {
     const int key = kt * 16 + c;
     const bool kvalid = key < N;
-    const float kb = kvalid ? 0.f : -INFINITY;
-    const bool kvalid_wave = kt * 16 + 16 <= N;           // wave-uniform: every key of this tile is real
-    const bf16x8 kf0 = scale_frag(row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), c2), kf1 = scale_frag(row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane), c2);
-    const bf16x8 vf0 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), vf1 = row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane);
+    const Frag4 cur = nxt;
+    if (kt + NW_BWD < nkt) nxt = load_kv(kt + NW_BWD);
+    const bf16x8 kf0 = scale_frag(cur.a0, c2), kf1 = scale_frag(cur.a1, c2);
+    const bf16x8 vf0 = cur.b0, vf1 = cur.b1;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int qs = 0; qs < nqs; ++qs) {
-      f32x4 pp[2], ds[2];
+#pragma unroll
+    for (int qs = 0; qs < NMAX / 32; ++qs) {
+      if (qs >= nqs) continue;
+      u32x4 pw, dsw;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int qt = 2 * qs + u;
-        // the chains start from -lse / -delta of this lane's 4 queries (stored negated in LDS: the loads ARE the C operands)
+        // the chains start from -lse / -delta of this lane's 4 queries (stored negated in LDS: the loads ARE the C operands).  Keys
+        // >= N of the last tile need no mask here: a key column only ever reaches its own dK / dV rows, which are not stored.
         f32x4 sv = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
         f32x4 dp = *reinterpret_cast<const f32x4*>(del_s + qt * 16 + 4 * g);
-        if (!kvalid_wave) {                      // last key tile only: lanes whose key is padding start at -inf
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sv[r] += kb;
-        }
         sv = MFMA16(RF(Qimg, qt, 0), kf0, sv);   // D[query = 4g + r][key = c]
         sv = MFMA16(RF(Qimg, qt, 1), kf1, sv);
         dp = MFMA16(RF(Dimg, qt, 0), vf0, dp);
         dp = MFMA16(RF(Dimg, qt, 1), vf1, dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(sv[r]);
-          pp[u][r] = p;
-          ds[u][r] = p * dp[r];
-        }
+        const f32x2 p01 = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])}, p23 = {__builtin_amdgcn_exp2f(sv[2]), __builtin_amdgcn_exp2f(sv[3])};
+        pw[2 * u] = cvt_pk(p01);
+        pw[2 * u + 1] = cvt_pk(p23);
+        dsw[2 * u] = cvt_pk(p01 * f32x2{dp[0], dp[1]});
+        dsw[2 * u + 1] = cvt_pk(p23 * f32x2{dp[2], dp[3]});
       }
-      const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         dv[dt] = MFMA16(TR(Dimg, qs, dt), pf, dv[dt]);    // dV^T[d][key]
