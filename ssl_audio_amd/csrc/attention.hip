@@ -80,6 +80,7 @@ typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
 __device__ __forceinline__ uint32_t cvt_pk(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
 __device__ __forceinline__ uint32_t cvt_pk(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MFMA16(x, y, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((x), (y), (c), 0, 0, 0)
 
@@ -191,80 +192,85 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
 }
 
 // =====================================================================================================
+// Backward.  Every byte of a head is read from global memory exactly once:
+//   * K and V rows go to two LDS images (LDS-DMA); each wave reads Q, dO and O rows of ITS query tiles as 16-byte row fragments --
+//     delta = rowsum(dO * O) falls out of those fragments (reduced over the four lanes that share a row), so there is no separate
+//     statistics pass and pass A (dQ, wave owns query tiles) starts from registers;
+//   * before the images are given up, each wave pulls the K, V fragments of ITS key tiles out of them (pass B's register operand);
+//   * the waves then write their Q / dO fragments into the same LDS (the Q and dO images of pass B: dK, dV, wave owns key tiles).
+// The version before this one re-staged Q / dO from global and fetched the pass-B fragments from global as well: 320 KB of reads
+// per head instead of 160, and with the compute loops removed it still took 70 % of its time -- the kernel was bound by that traffic.
 template <int NMAX>
 __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Two images at a time (NMAX = 256: 2 x 32 KiB, 66 KiB with the statistics -> two workgroups per CU): K,V during pass A, then the
-  // same LDS is re-staged with Q,dO for pass B.  The operand that is NOT in LDS is read as 16-byte row fragments from global.
-  constexpr int IMG = NMAX * HD * 2;
+  constexpr int IMG = NMAX * HD * 2;                 // NMAX = 256: 2 x 32 KiB + statistics = 66 KiB -> two workgroups per CU
+  constexpr int NT = NMAX / (16 * NW_BWD);           // 16-row tiles per wave (2 or 4): tile j of wave w is w + j * NW_BWD
   char* Kimg = smem;
   char* Vimg = smem + IMG;
   char* Qimg = smem;                                 // pass B reuses the two images
   char* Dimg = smem + IMG;                           // dO
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * IMG);
-  float* del_s = lse_s + NMAX;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * IMG);   // -lse in log2 units / -delta per query: the initial accumulators of
+  float* del_s = lse_s + NMAX;                                // the S and dP chains of pass B
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = blockIdx.x / H, h = blockIdx.x % H;
   const int64_t row_base = (int64_t)s * N;
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + row_base * ld, (uint32_t)(((total_rows - row_base - 1) * ld + 3 * C) * 2));
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(dout + row_base * ldo, (uint32_t)(((total_rows - row_base - 1) * ldo + C) * 2));
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(o + row_base * ldo, (uint32_t)(((total_rows - row_base - 1) * ldo + C) * 2));
 
-  const int nkt = (N + 15) >> 4;
-  const int nks = (N + 31) >> 5;
-  const int nrows = nks * 32;
-  // The operand a wave owns (Q, dO of its query tile in pass A; K, V of its key tile in pass B) comes straight from global as four
-  // 16-byte row fragments.  Each tile's fragments are requested one tile ahead -- the first ones here, ahead of the staging -- so
-  // that no tile starts with an exposed L2 / HBM round trip.
-  struct Frag4 { bf16x8 a0, a1, b0, b1; };
-  auto load_qd = [&](int qt) {
-    return Frag4{row_frag_global(rs, ld, qt * 16, h * HD, 0, lane), row_frag_global(rs, ld, qt * 16, h * HD, 1, lane),
-                 row_frag_global(rd, ldo, qt * 16, h * HD, 0, lane), row_frag_global(rd, ldo, qt * 16, h * HD, 1, lane)};
-  };
-  auto load_kv = [&](int kt) {
-    return Frag4{row_frag_global(rs, ld, kt * 16, C + h * HD, 0, lane), row_frag_global(rs, ld, kt * 16, C + h * HD, 1, lane),
-                 row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 0, lane), row_frag_global(rs, ld, kt * 16, 2 * C + h * HD, 1, lane)};
-  };
-  Frag4 nxt = load_qd(wave);
-  stage_rows(rs, Kimg, ld, C + h * HD, nrows, wave, lane, NW_BWD);
-  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nrows, wave, lane, NW_BWD);
-  // delta[q] = sum_d dO[q][d] * O[q][d], lse -> LDS.  Eight lanes share a query row (8 x 16 B = the row's 128 bytes of one head), so
-  // a wave instruction reads 8 whole row segments instead of 64 scattered 16-byte pieces (that version cost a quarter of the kernel).
+  const int g = lane >> 4, c = lane & 15;
+  const int nkt = (N + 15) >> 4;                       // 16-row tiles holding real rows
+  const int nks = (N + 31) >> 5;                       // 32-row steps: tiles [0, 2 * nks) exist in the images (rows >= N hold finite junk)
+  const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
+  const float c2 = scale * 1.44269504088896340736f;    // p = exp(scale*s - lse) = exp2(c2*s - lse*log2e)
+
+  stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane, NW_BWD);
+  stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane, NW_BWD);
+  // own query tiles: Q, dO (kept until they become the pass-B images) and O (only for delta).  Rows past N read the next
+  // sequence or zeros -- finite either way, and every use of them is multiplied by p = 0 or never stored.
+  bf16x8 qf[NT][2], df[NT][2];
+  float nl[NT], nd[NT];                                // -lse (log2 units), -delta of query tile j, row c
   {
-    const int sub = lane >> 3, ch = lane & 7;
-    constexpr int NIT = NMAX / (NW_BWD * 8);           // 4 row groups per wave: all 12 loads go out before the first is consumed
-    bf16x8 a[NIT], b[NIT];
-    float ls[NIT];
+    bf16x8 of[NT][2];
+    float ls[NT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = (it * NW_BWD + wave) * 8 + sub;
-      const int qc = q < nq ? q : 0;                    // clamp: the row is read but its result discarded
-      a[it] = *reinterpret_cast<const bf16x8*>(o + (row_base + qc) * ldo + h * HD + ch * 8);
-      b[it] = *reinterpret_cast<const bf16x8*>(dout + (row_base + qc) * ldo + h * HD + ch * 8);
-      ls[it] = lse[((int64_t)s * H + h) * N + qc];
+    for (int j = 0; j < NT; ++j) {
+      const int t = wave + j * NW_BWD;
+      if (t < 2 * nks) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[j][ks] = row_frag_global(rs, ld, t * 16, h * HD, ks, lane);
+          df[j][ks] = row_frag_global(rd, ldo, t * 16, h * HD, ks, lane);
+          of[j][ks] = row_frag_global(ro, ldo, t * 16, h * HD, ks, lane);
+        }
+        const int query = t * 16 + c;
+        ls[j] = lse[((int64_t)s * H + h) * N + (query < nq ? query : 0)];
+      }
     }
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = (it * NW_BWD + wave) * 8 + sub;
-      float dl = 0.f;
+    for (int j = 0; j < NT; ++j) {
+      const int t = wave + j * NW_BWD;
+      if (t < 2 * nks) {
+        float dl = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dl += bf2f(a[it][j]) * bf2f(b[it][j]);
-      dl += __shfl_xor(dl, 1, 64);
-      dl += __shfl_xor(dl, 2, 64);
-      dl += __shfl_xor(dl, 4, 64);
-      if (ch == 0) {
-        // both stored NEGATED: they are the initial accumulators of the S and dP chains.  queries >= nq: -lse = -inf makes every p exactly 0
-        del_s[q] = q < nq ? -dl : 0.f;
-        lse_s[q] = q < nq ? -ls[it] * 1.44269504088896340736f : -INFINITY;           // log2 units for v_exp
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dl += bf2f(df[j][ks][e]) * bf2f(of[j][ks][e]);
+        dl += __shfl_xor(dl, 16, 64);                  // the four lanes g = 0..3 of a row hold 16 of its 64 columns each
+        dl += __shfl_xor(dl, 32, 64);
+        const int query = t * 16 + c;
+        nl[j] = query < nq ? -ls[j] * 1.44269504088896340736f : -INFINITY;   // -inf: every p of an un-queried row is exactly 0
+        nd[j] = query < nq ? -dl : 0.f;
+        if (g == 0) { lse_s[query] = nl[j]; del_s[query] = nd[j]; }
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int g = lane >> 4, c = lane & 15;
   // per-lane LDS offsets, loop invariant: tile bases are multiples of 16 rows, so (row & 7) never depends on the tile
   const int rf0 = c * 128 + ((g ^ (c & 7)) << 4), rf1 = c * 128 + (((4 + g) ^ (c & 7)) << 4);       // row_frag, k-step 0 / 1
   int trf[4];                                                                                        // tr_frag, d-tile 0..3
@@ -282,86 +288,96 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     s16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
   };
-  const float c2 = scale * 1.44269504088896340736f;    // p = exp(scale*s - lse) = exp2(c2*s - lse*log2e)
 
   // ------------------------------------------------------------------ pass A: dQ (wave owns query tiles)
-  const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
-  for (int qt = wave; qt < nkt; qt += NW_BWD) {
-    const int query = qt * 16 + c;
-    const Frag4 cur = nxt;
-    if (qt + NW_BWD < nkt) nxt = load_qd(qt + NW_BWD);
-    if (qt >= nqt) {                                       // dQ of an un-queried tile is exactly zero
-      if (query < N) {
-        bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
-        const bf16x4 z = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = z;
-      }
-      continue;
-    }
-    const bf16x8 qf0 = scale_frag(cur.a0, c2), qf1 = scale_frag(cur.a1, c2);
-    const bf16x8 df0 = cur.b0, df1 = cur.b1;
-    // initial accumulators of the two chains (loop invariant, the MFMA's C operand): S' = c2 s - lse, dP' = dP - delta
-    const float nl = lse_s[query], nd = del_s[query];      // -lse (log2 units), -delta
-    const f32x4 s_init = {nl, nl, nl, nl}, d_init = {nd, nd, nd, nd};
+  for (int j = 0; j < NT; ++j) {
+    const int qt = wave + j * NW_BWD;
+    if (qt >= nkt) continue;
+    const int query = qt * 16 + c;
     f32x4 acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // one 32-key step.  Only the last step can hold keys >= N (they start at -inf so that p = 0); the others are unrolled with
-    // compile-time step numbers, so every LDS address is the lane's base register + an immediate.
-    auto step = [&](int ps, auto masked) {
-      u32x4 dsw;
+    if (qt < nqt) {                                          // dQ of an un-queried tile is exactly zero
+      // Q prescaled by scale * log2(e): with -lse as the chain's initial accumulator the scores come out as S' = c2 s - lse, and
+      // dP' = dP - delta likewise, so p = exp2(S') and dS = p * dP' need no further VALU
+      const bf16x8 qs0 = scale_frag(qf[j][0], c2), qs1 = scale_frag(qf[j][1], c2);
+      const bf16x8 df0 = df[j][0], df1 = df[j][1];
+      const float nlj = nl[j];
+      const f32x4 s_init = {nlj, nlj, nlj, nlj}, d_init = {nd[j], nd[j], nd[j], nd[j]};
+      // one 32-key step.  Only the last step can hold keys >= N (they start at -inf so that p = 0); the others are unrolled with
+      // compile-time step numbers, so every LDS address is the lane's base register + an immediate.
+      auto step = [&](int ps, auto masked) {
+        u32x4 dsw;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kt = 2 * ps + u;
-        f32x4 sv = s_init, dp;
-        if constexpr (decltype(masked)::value) {
+        for (int u = 0; u < 2; ++u) {
+          const int kt = 2 * ps + u;
+          f32x4 sv = s_init, dp;
+          if constexpr (decltype(masked)::value) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : nl;
+            for (int r = 0; r < 4; ++r) sv[r] = (kt * 16 + 4 * g + r >= N) ? -INFINITY : nlj;
+          }
+          sv = MFMA16(RF(Kimg, kt, 0), qs0, sv);
+          sv = MFMA16(RF(Kimg, kt, 1), qs1, sv);
+          dp = MFMA16(RF(Vimg, kt, 0), df0, d_init);
+          dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
+          const f32x2 p01 = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])}, p23 = {__builtin_amdgcn_exp2f(sv[2]), __builtin_amdgcn_exp2f(sv[3])};
+          dsw[2 * u] = cvt_pk(p01 * f32x2{dp[0], dp[1]});
+          dsw[2 * u + 1] = cvt_pk(p23 * f32x2{dp[2], dp[3]});
         }
-        sv = MFMA16(RF(Kimg, kt, 0), qf0, sv);
-        sv = MFMA16(RF(Kimg, kt, 1), qf1, sv);
-        dp = MFMA16(RF(Vimg, kt, 0), df0, d_init);
-        dp = MFMA16(RF(Vimg, kt, 1), df1, dp);
-        // p = exp2(S'): 0 for padding keys (-inf) and un-queried rows (-lse = -inf); dS = p * dP'; the softmax scale is applied once, to the accumulator
-        const f32x2 p01 = {__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])}, p23 = {__builtin_amdgcn_exp2f(sv[2]), __builtin_amdgcn_exp2f(sv[3])};
-        dsw[2 * u] = cvt_pk(p01 * f32x2{dp[0], dp[1]});
-        dsw[2 * u + 1] = cvt_pk(p23 * f32x2{dp[2], dp[3]});
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsw);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(TR(Kimg, ps, dt), dsf, acc[dt]);
+      };
+#pragma unroll
+      for (int ps = 0; ps < NMAX / 32 - 1; ++ps) {
+        if (ps >= nks - 1) continue;
+        step(ps, std::false_type{});
       }
-      const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsw);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = MFMA16(TR(Kimg, ps, dt), dsf, acc[dt]);
-    };
-#pragma unroll
-    for (int ps = 0; ps < NMAX / 32 - 1; ++ps) {
-      if (ps >= nks - 1) continue;
-      step(ps, std::false_type{});
+      step(nks - 1, std::true_type{});
     }
-    step(nks - 1, std::true_type{});
     if (query < N) {
       bf16_t* drow = dqkv + (row_base + query) * ld + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 v = {f2bf(acc[dt][0] * scale), f2bf(acc[dt][1] * scale), f2bf(acc[dt][2] * scale), f2bf(acc[dt][3] * scale)};
-        *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
-      }
+      for (int dt = 0; dt < 4; ++dt)     // the softmax scale is applied once, to the accumulator
+        *reinterpret_cast<u32x2*>(drow + dt * 16 + 4 * g) = u32x2{cvt_pk(acc[dt][0] * scale, acc[dt][1] * scale), cvt_pk(acc[dt][2] * scale, acc[dt][3] * scale)};
     }
   }
 
-  // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
-  nxt = load_kv(wave);
+  // ------------------------------------------------------------------ hand-over: K, V fragments out of the images, Q, dO fragments in
+  bf16x8 kf[NT][2], vf[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int kt = wave + j * NW_BWD;
+    if (kt < nkt) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { kf[j][ks] = RF(Kimg, kt, ks); vf[j][ks] = RF(Vimg, kt, ks); }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();                                   // every wave is done reading the K / V images
-  stage_rows(rs, Qimg, ld, h * HD, nqs * 32, wave, lane, NW_BWD);
-  stage_rows(rd, Dimg, ldo, h * HD, nqs * 32, wave, lane, NW_BWD);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int t = wave + j * NW_BWD;
+    if (t < 2 * nks) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        *reinterpret_cast<bf16x8*>(Qimg + t * 2048 + (ks ? rf1 : rf0)) = qf[j][ks];
+        *reinterpret_cast<bf16x8*>(Dimg + t * 2048 + (ks ? rf1 : rf0)) = df[j][ks];
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int kt = wave; kt < nkt; kt += NW_BWD) {
+
+  // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int kt = wave + j * NW_BWD;
+    if (kt >= nkt) continue;
     const int key = kt * 16 + c;
-    const bool kvalid = key < N;
-    const Frag4 cur = nxt;
-    if (kt + NW_BWD < nkt) nxt = load_kv(kt + NW_BWD);
-    const bf16x8 kf0 = scale_frag(cur.a0, c2), kf1 = scale_frag(cur.a1, c2);
-    const bf16x8 vf0 = cur.b0, vf1 = cur.b1;
+    const bf16x8 kf0 = scale_frag(kf[j][0], c2), kf1 = scale_frag(kf[j][1], c2);
+    const bf16x8 vf0 = vf[j][0], vf1 = vf[j][1];
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -393,15 +409,13 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
         dk[dt] = MFMA16(TR(Qimg, qs, dt), dsf, dk[dt]);   // dK^T[d][key]
       }
     }
-    if (kvalid) {
+    if (key < N) {
       bf16_t* krow = dqkv + (row_base + key) * ld + C + h * HD;
       bf16_t* vrow = krow + C;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 a = {f2bf(dk[dt][0] * scale), f2bf(dk[dt][1] * scale), f2bf(dk[dt][2] * scale), f2bf(dk[dt][3] * scale)};
-        bf16x4 b = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
-        *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
-        *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = b;
+        *reinterpret_cast<u32x2*>(krow + dt * 16 + 4 * g) = u32x2{cvt_pk(dk[dt][0] * scale, dk[dt][1] * scale), cvt_pk(dk[dt][2] * scale, dk[dt][3] * scale)};
+        *reinterpret_cast<u32x2*>(vrow + dt * 16 + 4 * g) = u32x2{cvt_pk(dv[dt][0], dv[dt][1]), cvt_pk(dv[dt][2], dv[dt][3])};
       }
     }
   }
