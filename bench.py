@@ -30,6 +30,7 @@ GF_PER_CLIP = {"vit_base_bt_10s": 268.2, "vit_tiny_bt_10s": 19.5, "vit_base_byol
                # config 5 as main.py runs it: view 1 masked (63 tokens) + decoder, view 2 UNMASKED ViT-L: 3 * (156.6 + 38.6 + 4.0) GF
                "vit_large_mae_10s": 597.6}
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CUs x 256 FLOP/clk x 2.4 GHz (fp32 vector, FMA)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy)
 
 
@@ -238,13 +239,18 @@ def main():
         exec_gf = executed_gflop_per_clip(model_type, mode, n_tok)
         hbm_kernels = {}
         for kname, recs in (sprof or {}).items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-            nb = sum(b for _, _, b in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            nb = sum(r[2] for r in recs)
+            fl = sum(r[3] for r in recs)
             if ms > 0:
                 gbs = nb / (ms * 1e-3) / 1e9
                 hbm_kernels[kname] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                       "launches": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
                                       "algorithmic_bytes_per_launch": round(nb / len(recs)), "share_of_step": round(ms / (dt * 1e3), 4)}
+                if fl > 0:     # arithmetic outweighs bytes (the FFT frontend: 87 flop per byte): the fp32 vector rate is the nearer bound
+                    tf = fl / (ms * 1e-3) / 1e12
+                    hbm_kernels[kname]["nearer_bound"] = {"bound": "valu_f32", "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                                          "frac": round(tf / PEAK_F32_VALU_TFLOPS, 4), "algorithmic_flop_per_launch": round(fl / len(recs))}
         line = {
             "metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

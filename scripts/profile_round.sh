@@ -4,8 +4,6 @@
 #   dominant GEMM kernels, the per-block GEMM table and the hipBLASLt bar.   usage: bash scripts/profile_round.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02; mkdir -p $O
-python3 bench.py --steps 20 --warmup 5 > $O/bench_vitb_b128_line.json 2> $O/bench_vitb_b128.err || exit 1
-echo "bench done"; tail -c 600 $O/bench_vitb_b128_line.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python3 bench.py --steps 5 --warmup 2 --no_cpu_baseline > $O/ktrace.log 2>&1 || exit 1
 cp $(ls $O/ktrace/*/*kernel_stats.csv | head -1) $O/bench_vitb_b128_kernel_stats.csv 2>/dev/null
 echo "kernel trace done"
@@ -15,6 +13,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 scripts/traffic_summary.py gpurun_out/traffic $O/gemm_traffic.json > $O/gemm_traffic_summary.txt 2>&1
 echo "traffic done"; cat $O/gemm_traffic_summary.txt | cut -c1-400
+cp $O/gemm_traffic.json profiles/r02_gemm_traffic.json   # (the box-local copy: the bench line below embeds the traffic of THIS tree)
+python3 bench.py --steps 20 --warmup 5 > $O/bench_vitb_b128_line.json 2> $O/bench_vitb_b128.err || exit 1
+echo "bench done"; tail -c 600 $O/bench_vitb_b128_line.json
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM"; do
   n=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_r02/$n -- python3 scripts/bench_gemm.py "N" 2 > $O/pmc_$n.log 2>&1 || exit 1

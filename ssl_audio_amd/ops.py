@@ -16,8 +16,9 @@ GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end e
 STREAM_PROFILE = None  # set to a dict by bench.py: kernel name -> [(start event, end event, algorithmic bytes)] for the HBM-bound front kernels
 
 
-def _timed(name, nbytes, launch):
-    """bench.py's roofline leg for the HBM-bound kernels: HIP events on the launch stream around one launch."""
+def _timed(name, nbytes, launch, flops=0.0):
+    """bench.py's roofline leg for the HBM-bound kernels: HIP events on the launch stream around one launch
+    (flops: fp32 vector work of the launch, for a kernel whose arithmetic outweighs its bytes)."""
     if STREAM_PROFILE is None:
         launch()
         return
@@ -25,7 +26,7 @@ def _timed(name, nbytes, launch):
     e0.record()
     launch()
     e1.record()
-    STREAM_PROFILE.setdefault(name, []).append((e0, e1, float(nbytes)))
+    STREAM_PROFILE.setdefault(name, []).append((e0, e1, float(nbytes), float(flops)))
 
 
 def _stream():
@@ -304,7 +305,9 @@ def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop):
     _timed("logmel_kernel", 4.0 * B * L + 4.0 * B * 64 * T_out, lambda: check(
         lib().sa_logmel_fwd(_p(_req(wave, F32, "wave")), wave.stride(0), B, L, _p(tables["window"]), _p(tables["twiddle"]),
                             _p(tables["mel_weights"]), _p(tables["mel_lo"]), _p(tables["mel_len"]), _p(_req(out, F32, "out")),
-                            out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd"))
+                            out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd"),
+           # per frame: 1024-point FFT (5 N log2 N), window, 513 power bins (3 each), the <= 2 mel bands of every bin (2 x 2 each)
+           flops=float(B) * T_out * (5.0 * 1024 * 10 + 1024 + 3 * 513 + 4 * 513))
 
 
 def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in, canvas, max_w_ratio, do_fade):
