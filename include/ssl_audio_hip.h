@@ -62,8 +62,14 @@ typedef struct SaGemmArgs {
                                    produced this GEMM's A operand's gradient, e.g. fc1's bias from the fc2 dgrad: utils of
                                    models/mae.py:155 backward).  Needs split_k == 1, N % 64 == 0 and colsum_ws. */
   float* colsum_ws;             /* scratch of sa_gemm_colsum_workspace_bytes(M, N) bytes */
+  float* splitk_ws;             /* optional, split_k > 1 only: scratch of sa_gemm_splitk_workspace_bytes(M, N, split_k) bytes.  When
+                                   given, every K slice STORES its partial tile there and a second launch adds the slices into
+                                   out_f32 in slice order: the result is bit-reproducible from run to run (the atomic path is
+                                   exact only up to the fp32 rounding of an arbitrary summation order).  Served by the two default
+                                   split-K kernels (128 x 128 and tile256) */
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
+int64_t sa_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
 /* Host policy knob (no reference counterpart): CUs the persistent GEMM grids may occupy, 0 = all.  Data-parallel runs reserve
  * the CUs RCCL's collective kernels hold during an all-reduce, so an overlapped GEMM does not spill into a second wave. */

@@ -29,6 +29,7 @@ class SaGemmArgs(C.Structure):
         ("out_bf16", P), ("ldo_bf16", I64),
         ("row_group", I32), ("split_k", I32), ("accumulate", I32), ("tile256", I32),
         ("colsum_out", P), ("colsum_ws", P),
+        ("splitk_ws", P),
     ]
 
 
@@ -44,6 +45,7 @@ _SIGNATURES = {
     "sa_set_cu_budget": [I32],
     "sa_lars_step": [P, P, P, I64, F32, F32, F32, F32, I32, P, P, P],
     "sa_gemm_colsum_workspace_bytes": [I32, I32],
+    "sa_gemm_splitk_workspace_bytes": [I32, I32, I32],
     "sa_mix_gaussian_noise": [P, P, I64, F32, F32, P, P],
     "sa_running_norm": [P, I32, I64, P, I32, I32, F32, P, P],
     "sa_token_group_sum": [P, I32, I32, I32, I32, I32, I32, I32, F32, I32, P, P],

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   const int chunk = (ksteps + p.split_k - 1) / p.split_k;
   const int kt_begin = ks_id * chunk;
   const int kt_end = min(ksteps, kt_begin + chunk);
-  if (kt_begin >= kt_end) return;  // (only possible for split_k > 1: nothing to add)
+  if (kt_begin >= kt_end) return;  // (only possible for split_k > 1: nothing to add; the deterministic reduce skips empty slices)
 
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
@@ -106,7 +106,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+          if (m < p.M && n < p.N) {
+            if (p.split_ws) p.split_ws[((int64_t)ks_id * p.M + m) * p.N + n] = p.alpha * acc[i][j][r];
+            else atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+          }
         }
       }
   } else {
@@ -239,7 +242,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wr * 128 + i * 16 + 4 * g + r;
-          if (m < p.M && n < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+          if (m < p.M && n < p.N) {
+            if (p.split_ws) p.split_ws[((int64_t)ks_id * p.M + m) * p.N + n] = p.alpha * acc[i][j][r];
+            else atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+          }
         }
       }
     return;
@@ -914,6 +920,29 @@ extern "C" int sa_set_cu_budget(int32_t cus) {
 
 extern "C" int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)((M + 63) / 64) * N * (int64_t)sizeof(float); }
 
+namespace {
+// deterministic split-K, second launch: out[m][n] += ws[0][m][n] + ws[1][m][n] + ... in slice order (one thread per 4 columns)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nslice, int M, int N, float* __restrict__ out, int64_t ldo) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i4 >= (int64_t)M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 - (int64_t)m * n4) * 4;
+  float4 acc = *reinterpret_cast<const float4*>(ws + (int64_t)m * N + n);
+  for (int s = 1; s < nslice; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + ((int64_t)s * M + m) * N + n);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float4* o = reinterpret_cast<float4*>(out + (int64_t)m * ldo + n);
+  float4 t = *o;
+  t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+  *o = t;
+}
+}  // namespace
+
+extern "C" int64_t sa_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+  return (M > 0 && N > 0 && split_k > 1) ? (int64_t)split_k * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SA_CHECK_ARG(a != nullptr, "sa_gemm_bf16: null args");
@@ -923,7 +952,16 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
                      (!a->aux_out || (a->ldaux % 8 == 0 && ((uintptr_t)a->aux_out & 15) == 0)),
                  "sa_gemm_bf16: colsum_out needs 16-byte aligned bf16 outputs with leading dimensions that are multiples of 8");
   }
+  if (a->splitk_ws)
+    SA_CHECK_ARG(a->split_k > 1 && a->N % 4 == 0 && ((uintptr_t)a->splitk_ws & 15) == 0, "sa_gemm_bf16: splitk_ws needs split_k > 1, N %% 4 == 0 and a 16-byte aligned workspace");
   const int rc = gemm_dispatch(a, stream);
+  if (rc == 0 && a->splitk_ws) {
+    const int64_t n4 = (int64_t)a->M * (a->N / 4);
+    const int ksteps = (a->K + BK - 1) / BK, chunk = (ksteps + a->split_k - 1) / a->split_k;
+    const int nslice = (ksteps + chunk - 1) / chunk;         // trailing slices with an empty K range wrote nothing
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->splitk_ws, nslice, a->M, a->N, a->out_f32, a->ldo_f32);
+    SA_LAUNCH_CHECK("sa_gemm_bf16(split-K reduce)");
+  }
   if (rc != 0 || !a->colsum_out) return rc;
   hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3(a->N / 64), dim3(1024), 0, stream, a->colsum_ws, (a->M + 63) / 64, a->N, a->colsum_out);
   SA_LAUNCH_CHECK("sa_gemm_bf16(colsum reduce)");
@@ -971,6 +1009,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.out_bf16 = (bf16_t*)a->out_bf16; p.ldo_bf16 = a->ldo_bf16;
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
+  p.split_ws = a->split_k > 1 ? a->splitk_ws : nullptr;
   static const char* es_env = getenv("SA_GEMM_EPI_COMPACT");
   p.epi_kind = 0;
   {
@@ -1039,10 +1078,10 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     static const char* wphase = getenv("SA_GEMM_WGRAD_PHASE");
-    if (wphase && wphase[0] == '1' && !a->a_kmajor && !a->b_kmajor && (a->K + BK - 1) / BK / a->split_k >= 2)
+    if (!p.split_ws && wphase && wphase[0] == '1' && !a->a_kmajor && !a->b_kmajor && (a->K + BK - 1) / BK / a->split_k >= 2)
       return sagemm::launch_phase(p, false, false, true, stream);
     static const char* wring = getenv("SA_GEMM_WGRAD_RING");
-    if (wring && wring[0] == '1') {
+    if (!p.split_ws && wring && wring[0] == '1') {
       if (a->a_kmajor && a->b_kmajor) return launch256_ring<true, true, true>(p, stream);
       if (a->a_kmajor && !a->b_kmajor) return launch256_ring<true, false, true>(p, stream);
       if (!a->a_kmajor && a->b_kmajor) return launch256_ring<false, true, true>(p, stream);

@@ -30,6 +30,7 @@ struct GemmParams {
   bf16_t* out_bf16; int64_t ldo_bf16;
   int row_group;
   int split_k; int accumulate;
+  float* split_ws;   // deterministic split-K: slice s stores alpha * partial into split_ws[(s * M + m) * N + n] instead of atomically adding to out_f32
   int tiles_m, tiles_n;
   int gm;   // row-panels per tile group (L2 locality knob)
   int gm256;         // row-panels per tile group in the 256^2 kernels

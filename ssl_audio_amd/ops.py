@@ -5,6 +5,8 @@ hot path goes through libssl_audio_hip.so.  All calls are enqueued on torch's cu
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -12,6 +14,10 @@ from ._lib import SaGemmArgs, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+# Weight gradients are split-K sums.  By default the K slices add into the gradient buffer with fp32 atomics (fastest; exact up to the
+# rounding of an arbitrary summation order, so not bit-reproducible from run to run); with DETERMINISTIC_WGRAD (or SA_DETERMINISTIC=1)
+# every slice stores its partial tile in a workspace and a second launch adds the slices in slice order.
+DETERMINISTIC_WGRAD = os.environ.get("SA_DETERMINISTIC", "0") == "1"
 GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end event, flops, layout) per GEMM launch
 STREAM_PROFILE = None  # set to a dict by bench.py: kernel name -> [(start event, end event, algorithmic bytes)] for the HBM-bound front kernels
 
@@ -81,6 +87,8 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     if out_bf16 is not None:
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
     a.row_group, a.split_k, a.accumulate, a.tile256 = row_group, split_k, int(accumulate), int(tile256)
+    if split_k > 1 and DETERMINISTIC_WGRAD and N % 4 == 0:
+        a.splitk_ws = _workspace(lib().sa_gemm_splitk_workspace_bytes(M, N, split_k), A.device, "gemm_splitk").data_ptr()
     if colsum_out is not None:          # colsum_out[n] += sum_m (fp32 epilogue result)[m][n], through a scratch of per-64-row partials
         ws = _workspace(lib().sa_gemm_colsum_workspace_bytes(M, N), A.device, "gemm_colsum")
         a.colsum_out, a.colsum_ws = _req(colsum_out, F32, "colsum_out").data_ptr(), ws.data_ptr()

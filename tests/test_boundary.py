@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in syms if not hasattr(h, s)]
     assert not missing, missing
     h.sa_abi_version.restype = ctypes.c_int
-    assert h.sa_abi_version() == 2
+    assert h.sa_abi_version() == 3
     # every declared function has ctypes argument types (a missing entry would silently pass ints as 32-bit)
     assert [s for s in syms if s not in _lib._SIGNATURES and s != "sa_last_error"] == []
 

@@ -116,6 +116,30 @@ def test_gemm_split_k_wgrad(dev):
     assert rel_err(out, 0.5 * (dY.double().T @ X.double())) < 1e-5
 
 
+@pytest.mark.parametrize("tile256", [False, True])
+def test_gemm_split_k_deterministic(dev, tile256, monkeypatch):
+    """The workspace form of split-K (VERDICT r1 hygiene item: a deterministic wgrad reduction): slices are stored and added in slice
+    order, so two runs are bit-identical, the result accumulates into out_f32 like the atomic form and equals it to fp32 rounding.
+    Sizes: ragged M / N tiles, a K whose last slice is short and one whose trailing slice is empty (K = 9 steps over 5 slices)."""
+    monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", True)
+    for Mtok, N, K, split in [(3000, 320, 520, 5), (9 * 64, 256, 384, 5), (63744 // 8, 768, 768, 7)]:
+        dY = bf(rnd((Mtok, N), 83)).to(dev); X = bf(rnd((Mtok, K), 84)).to(dev)
+        base = torch.randn(N, K, device=dev)
+        outs = []
+        for _ in range(2):
+            out = base.clone()
+            ops.gemm(dY, X, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=tile256, alpha=0.5)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        ref = base.double().cpu() + 0.5 * (dY.double().cpu().T @ X.double().cpu())
+        assert rel_err(outs[0], ref) < 1e-5
+        monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", False)
+        out = base.clone()
+        ops.gemm(dY, X, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=tile256, alpha=0.5)
+        monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", True)
+        assert rel_err(out, outs[0].double().cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("env", [{}, {"SA_GEMM_TILE": "6"}, {"SA_GEMM_TILE": "8", "SA_GEMM_WGRAD_RING": "1"}, {"SA_GEMM_TILE": "1"},
                                  {"SA_GEMM_TILE": "A", "SA_GEMM_WGRAD_PHASE": "1"}])
 def test_gemm_tile_modes(dev, env):
