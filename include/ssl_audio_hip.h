@@ -272,6 +272,25 @@ int sa_frames_to_nhwc(const float* da, int64_t lda, const float* db, int64_t ldb
 int sa_meanmax_time_fwd(const float* x, int32_t B, int32_t T, int32_t D, float* out, int32_t* arg, void* stream);
 int sa_meanmax_time_bwd(const float* dout, const int32_t* arg, int32_t B, int32_t T, int32_t D, float* dx, void* stream);
 
+/* ------------------------------------------------------------------ ResNet-18 encoders (models/resnet.py: `resnet18`, `resnet18_ReGP_NRF`;
+ * BASELINE config 1), channel-last like the stems above.  The 3x3 convolutions are sa_im2col3x3_bf16 + sa_gemm_bf16, the 1x1
+ * downsample convolutions sa_subsample_fwd + sa_gemm_bf16, BatchNorm2d the sa_bn_*_tall kernels; these are the remaining pieces.
+ *   maxpool3s2 : MaxPool2d(3, stride 2, padding 1) (models/resnet.py:191); H_out = (H - 1) / 2 + 1.  idx[m][c] = ky*3 + kx of the first
+ *                maximum; the backward SUMS over the (overlapping) windows that recorded a pixel and writes every dx element
+ *   subsample  : y[b][oy][ox] = x[b][oy*sh][ox*sw] (input rows of a 1x1 convolution with stride, :223-226); bwd_add: dx at the sampled
+ *                pixels += dy (bf16, leading dimension lddy: the dgrad GEMM's padded output)
+ *   add_relu   : y = max(z + identity, 0) -> fp32 and (optional) bf16    (BasicBlock.forward :75-78, z = bn2(conv2(.)))
+ *   relu_bwd   : ds = y > 0 ? dy + dy2 : 0 (dy2 optional: the gradient arriving over the next block's identity path)
+ *   avgpool    : AdaptiveAvgPool2d((1, 1)) + flatten (:266-268): out[b][c] = mean over the L = H*W rows; bwd writes dx = dout / L */
+int sa_maxpool3s2_fwd(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, void* y_bf16, float* y_f32, uint8_t* idx, void* stream);
+int sa_maxpool3s2_bwd(const float* dy, const uint8_t* idx, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
+int sa_subsample_fwd(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t sh, int32_t sw, void* y_bf16, void* stream);
+int sa_subsample_bwd_add(const void* dy_bf16, int64_t lddy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t sh, int32_t sw, float* dx, void* stream);
+int sa_add_relu_fwd(const float* z, const float* identity, int64_t n, float* y_f32, void* y_bf16, void* stream);
+int sa_relu_bwd(const float* dy, const float* dy2, const float* y, int64_t n, float* ds, void* stream);
+int sa_avgpool_fwd(const float* x, int32_t B, int32_t L, int32_t C, float* out, void* stream);
+int sa_avgpool_bwd(const float* dout, int32_t B, int32_t L, int32_t C, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

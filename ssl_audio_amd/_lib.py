@@ -56,6 +56,14 @@ _SIGNATURES = {
     "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, P, P, P],
     "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P],
     "sa_mae_recon_loss_finalize": [P, P, P],
+    "sa_maxpool3s2_fwd": [P, I32, I32, I32, I32, P, P, P, P],
+    "sa_maxpool3s2_bwd": [P, P, I32, I32, I32, I32, P, P],
+    "sa_subsample_fwd": [P, I32, I32, I32, I32, I32, I32, P, P],
+    "sa_subsample_bwd_add": [P, I64, I32, I32, I32, I32, I32, I32, P, P],
+    "sa_add_relu_fwd": [P, P, I64, P, P, P],
+    "sa_relu_bwd": [P, P, P, I64, P, P],
+    "sa_avgpool_fwd": [P, I32, I32, I32, P, P],
+    "sa_avgpool_bwd": [P, I32, I32, I32, P, P],
     "sa_conv3x3_c1_fwd": [P, I32, I32, I32, I32, I32, P, P, I32, P, P],
     "sa_conv3x3_c1_wgrad": [P, I32, I32, I32, I32, I32, P, I32, P, P, P],
     "sa_im2col3x3_bf16": [P, I32, I32, I32, I32, I32, I32, P, I32, P],

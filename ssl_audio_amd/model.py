@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import mae
+from . import resnet
 from .audiontt import AudioNTT2022, AudioNTT2022Encoder  # noqa: F401  (model.py:130-177 of the reference defines them here)
 
 
@@ -64,7 +65,13 @@ class ModelWrapper(nn.Module):
         self._setup_model()
 
     def _setup_model(self):
-        if self.cfg.model_type == 'audiontt':
+        if self.cfg.model_type == 'resnet18':                     # model.py:74-77
+            self.encoder = resnet.resnet18()
+            self.encoder.embed_dim = 512
+        elif self.cfg.model_type == 'resnet18_ReGP_NRF':          # model.py:78-81
+            self.encoder = resnet.resnet18_ReGP_NRF()
+            self.encoder.embed_dim = 4096
+        elif self.cfg.model_type == 'audiontt':
             assert self.cfg.n_mels == 64, f'n_mels must be 64 to use AudioNTT encoder (n_mels set to {self.cfg.n_mels})'
             self.encoder = AudioNTT2022(squeeze_excitation=self.cfg.squeeze_excitation)
         elif 'vit' in self.cfg.model_type:
@@ -82,7 +89,7 @@ class ModelWrapper(nn.Module):
                 img_size=(self.cfg.n_mels, self.cfg.crop_frames) if (self.cfg.masked_recon and self.cfg.crop_frames % 16 == 0) else None,
             )
         else:
-            # resnet* encoders run on stock ops in the reference (BASELINE config 1: CPU plumbing) and are not part of this hot path
+            # the Bottleneck networks (resnet50, resnet50_ReGP_NRF) are not built on this path; unknown names raise as model.py:97 does
             raise NotImplementedError(f'Model type {self.cfg.model_type} is not supported on the MI355X hot path')
         self.feature_dim = self.encoder.embed_dim
 

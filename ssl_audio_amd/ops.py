@@ -503,3 +503,43 @@ def device_info():
     cus = C.c_int32(0)
     check(lib().sa_device_info(name, 128, C.byref(cus)), "sa_device_info")
     return name.value.decode(), cus.value
+
+
+# ------------------------------------------------------------------------------------------------ ResNet pieces (resnet.hip)
+def pool_out_size(n):
+    """MaxPool2d(3, stride 2, padding 1)."""
+    return (n - 1) // 2 + 1
+
+
+def maxpool3s2_fwd(x16, B, H, W, C, y16, y32, idx):
+    check(lib().sa_maxpool3s2_fwd(_p(_req(x16, BF16, "x")), B, H, W, C, _p(_req(y16, BF16, "y")), _p(y32), _p(idx), _stream()), "sa_maxpool3s2_fwd")
+
+
+def maxpool3s2_bwd(dy, idx, B, H, W, C, dx):
+    check(lib().sa_maxpool3s2_bwd(_p(_req(dy, F32, "dy")), _p(idx), B, H, W, C, _p(_req(dx, F32, "dx")), _stream()), "sa_maxpool3s2_bwd")
+
+
+def subsample_fwd(x16, B, H, W, C, stride, y16):
+    check(lib().sa_subsample_fwd(_p(_req(x16, BF16, "x")), B, H, W, C, stride[0], stride[1], _p(_req(y16, BF16, "y")), _stream()), "sa_subsample_fwd")
+
+
+def subsample_bwd_add(dy16, B, H, W, C, stride, dx):
+    check(lib().sa_subsample_bwd_add(_p(_req(dy16, BF16, "dy")), _rows(dy16, "dy")[2], B, H, W, C, stride[0], stride[1], _p(_req(dx, F32, "dx")),
+                                     _stream()), "sa_subsample_bwd_add")
+
+
+def add_relu_fwd(z, identity, y_f32, y_bf16=None):
+    check(lib().sa_add_relu_fwd(_p(_req(z, F32, "z")), _p(_req(identity, F32, "identity")), z.numel(), _p(_req(y_f32, F32, "y")), _p(y_bf16), _stream()),
+          "sa_add_relu_fwd")
+
+
+def relu_bwd(dy, dy2, y, ds):
+    check(lib().sa_relu_bwd(_p(_req(dy, F32, "dy")), _p(dy2), _p(_req(y, F32, "y")), y.numel(), _p(_req(ds, F32, "ds")), _stream()), "sa_relu_bwd")
+
+
+def avgpool_fwd(x, B, L, C, out):
+    check(lib().sa_avgpool_fwd(_p(_req(x, F32, "x")), B, L, C, _p(_req(out, F32, "out")), _stream()), "sa_avgpool_fwd")
+
+
+def avgpool_bwd(dout, B, L, C, dx):
+    check(lib().sa_avgpool_bwd(_p(_req(dout, F32, "dout")), B, L, C, _p(_req(dx, F32, "dx")), _stream()), "sa_avgpool_bwd")

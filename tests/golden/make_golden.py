@@ -603,7 +603,50 @@ def gen_audiontt():
     save("audiontt", **out)
 
 
+def gen_resnet():
+    """ResNet-18 encoders (models/resnet.py) in train mode, `fc` replaced by Identity as model.py:74-81 does: `resnet18` and
+    `resnet18_ReGP_NRF`.  The 11 M weights are not stored: they come from oracle.resnet.init_state(variant, seed) (the reference's
+    initialisation scheme from an explicit generator) and are LOADED into the reference model with strict key checking, so the fixture
+    pins key names and shapes too.  Stored: input, embedding, gradients of the small parameters, the gradient norm of every parameter,
+    BatchNorm buffers after the step."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import resnet as oresnet
+    from models import resnet as ref_resnet
+    out = {}
+    for variant, ctor in [("resnet18", ref_resnet.resnet18), ("resnet18_ReGP_NRF", ref_resnet.resnet18_ReGP_NRF)]:
+        m = ctor()
+        m.fc = nn.Identity()
+        sd = oresnet.init_state(variant, seed=3, affine_seed=11)
+        full = dict(sd)
+        for k in list(m.state_dict().keys()):
+            if k.endswith("num_batches_tracked"):
+                full[k] = torch.zeros((), dtype=torch.long)
+        m.load_state_dict(full, strict=True)
+        m.train()
+        torch.manual_seed(21)
+        x = torch.randn(4, 1, 64, 96) * 1.3 + 0.2
+        y = m(x)
+        w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+        m.zero_grad()
+        (y * w).sum().backward()
+        out[f"{variant}.x"], out[f"{variant}.y"] = t2n(x), t2n(y)
+        names, norms = [], []
+        for n, prm in m.named_parameters():
+            names.append(n)
+            norms.append(float(prm.grad.double().norm()))
+            if prm.numel() <= 40000:
+                out[f"{variant}.grad.{n}"] = t2n(prm.grad)
+        out[f"{variant}.grad_names"] = np.array(names)
+        out[f"{variant}.grad_norms"] = np.array(norms)
+        for k, v in m.state_dict().items():
+            if ("running" in k or "num_batches" in k) and (k.startswith("conv1.") or k.startswith("layer1.0.") or k.startswith("layer4.1.") or "downsample" in k):
+                out[f"{variant}.after.{k}"] = t2n(v)
+        out[f"{variant}.affine_seed"] = np.array([3, 11])
+    save("resnet", **out)
+
+
 if __name__ == "__main__":
+    gen_resnet() if "resnet" in sys.argv[1:] else None
     gen_convstem() if "convstem" in sys.argv[1:] else None
     gen_audiontt() if "audiontt" in sys.argv[1:] else None
     if len(sys.argv) > 1:

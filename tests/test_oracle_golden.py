@@ -402,3 +402,32 @@ def test_audiontt_oracle_golden(golden):
     for l, (mu, var, n) in enumerate(st):
         rv = 0.9 * sd[f"features.{4 * l + 1}.running_var"] + 0.1 * var * n / (n - 1)
         np.testing.assert_allclose(rv.numpy(), g[f"after.features.{4 * l + 1}.running_var"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["resnet18", "resnet18_ReGP_NRF"])
+def test_resnet_oracle_matches_reference(golden, variant):
+    """oracle/resnet.py == models/resnet.py (`fc` = Identity, train mode) on the fixture the reference produced: embedding, gradients of
+    the small parameters, gradient norms of all 62, BatchNorm buffers after the step (tests/golden/resnet.npz)."""
+    from oracle import resnet as oresnet
+    g = golden("resnet")
+    seed, aseed = [int(v) for v in g[f"{variant}.affine_seed"]]
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in oresnet.init_state(variant, seed, aseed).items()}
+    x = torch.from_numpy(g[f"{variant}.x"])
+    stats = []
+    y = oresnet.forward(x, p, variant, bn_stats=stats)
+    ref = torch.from_numpy(g[f"{variant}.y"])
+    assert y.shape == ref.shape and float((y.detach() - ref).norm() / ref.norm()) < 2e-5
+    w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    (y * w).sum().backward()
+    names = [str(n) for n in g[f"{variant}.grad_names"]]
+    assert names == [k for k in p if p[k].requires_grad]                       # parameter order == named_parameters() of the reference
+    for n, nrm in zip(names, g[f"{variant}.grad_norms"]):
+        assert abs(float(p[n].grad.double().norm()) - nrm) <= 2e-4 * max(nrm, 1e-6) + 1e-7, n
+        key = f"{variant}.grad.{n}"
+        if key in g:
+            assert float((p[n].grad - T(g[key])).norm() / T(g[key]).norm()) < 5e-4, n
+    for name, mean, var, cnt in stats:                                          # running buffers: momentum 0.1, unbiased variance
+        key = f"{variant}.after.{name}.running_mean"
+        if key in g:
+            assert np.allclose(0.1 * mean.numpy(), g[key], rtol=1e-4, atol=1e-6), name
+            assert np.allclose(0.9 + 0.1 * var.numpy() * cnt / (cnt - 1), g[f"{variant}.after.{name}.running_var"], rtol=1e-4, atol=1e-6), name
