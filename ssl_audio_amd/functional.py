@@ -174,6 +174,19 @@ def _bn_forward_stats(h, eps, running_mean, running_var):
     return mean, rstd
 
 
+def _gemm_f32_long_k(A16, W16, out, b_kmajor=True):
+    """out = A W^T (or A W) in fp32 for the projector's small-batch GEMMs: a few hundred rows against an 8192-long reduction is one or
+    two output tiles walking 128 K-steps on six CUs (130 us); splitting the reduction over the chip brings it to the launch floor."""
+    M, K = A16.shape
+    N = W16.shape[0] if b_kmajor else W16.shape[1]
+    split = ops.pick_split_k(M, N, K)
+    if split > 1:
+        out.zero_()
+        ops.gemm(A16, W16, b_kmajor=b_kmajor, out_f32=out, split_k=split)
+    else:
+        ops.gemm(A16, W16, b_kmajor=b_kmajor, out_f32=out)
+
+
 class MlpBnReluFn(torch.autograd.Function):
     """One crop chunk through Linear(nb) -> BN1d(train, affine) -> ReLU -> Linear(nb)  (model.py:16-23,39-45).
     With a process group the BN is a SyncBN over the global chunk (utils/utils.py:411)."""
@@ -189,7 +202,7 @@ class MlpBnReluFn(torch.autograd.Function):
         a = torch.empty(B, w0.shape[0], dtype=BF16, device=dev)
         ops.bn_apply(h, mean, rstd, gamma.detach(), beta.detach(), True, y_bf16=a)
         z = torch.empty(B, w1.shape[0], device=dev)
-        ops.gemm(a, BF16_WEIGHTS.get(w1), out_f32=z)
+        _gemm_f32_long_k(a, BF16_WEIGHTS.get(w1), z)
         ctx.save_for_backward(x16, h, mean, rstd, a, w0, gamma, beta, w1)
         return z
 
@@ -218,7 +231,7 @@ class MlpBnReluFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, w0.shape[1], device=dev)
-            ops.gemm(dh, BF16_WEIGHTS.get(w0), b_kmajor=False, out_f32=dx)
+            _gemm_f32_long_k(dh, BF16_WEIGHTS.get(w0), dx, b_kmajor=False)
         return dx, dw0, dgamma, dbeta, dw1, None, None
 
 

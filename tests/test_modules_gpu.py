@@ -196,8 +196,10 @@ def test_param_counts_and_keys():
     for k in ["cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.0.attn.q_bias",
               "blocks.11.mlp.fc2.bias", "norm.weight"]:
         assert k in keys
-    with pytest.raises(NotImplementedError):
-        model.ModelWrapper(hp.make_args(model_type="resnet18"))
+    assert model.ModelWrapper(hp.make_args(model_type="resnet18")).feature_dim == 512          # model.py:74-77
+    assert model.ModelWrapper(hp.make_args(model_type="resnet18_ReGP_NRF")).feature_dim == 4096  # model.py:78-81
+    with pytest.raises(NotImplementedError):                                                    # the Bottleneck networks are not built
+        model.ModelWrapper(hp.make_args(model_type="resnet50"))
 
 
 # ------------------------------------------------------------------------------------------------ whole step through the generic modules
