@@ -7,8 +7,9 @@ from ssl_audio_amd import ops, hyperparameters as hp
 from ssl_audio_amd.train import BarlowTwinsTrainer
 
 dev = torch.device("cuda:0")
-B, T = 128, 1001
-cfg = hp.make_args(model_type="vit_base", batch_size=B, crop_frames=T, dataset="audioset")
+size = sys.argv[1] if len(sys.argv) > 1 else "base"
+B, T = (256 if size == "tiny" else 128), 1001
+cfg = hp.make_args(model_type="vit_" + size, batch_size=B, crop_frames=T, dataset="audioset")
 tr = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=B, clip_samples=160000, seed=0, from_waveform=False)
 g = torch.Generator().manual_seed(0)
 views = [torch.randn(B, 1, 64, T, generator=g).to(dev) for _ in range(2)]

@@ -159,7 +159,7 @@ def pick_split_k(M, N, K, cu_count=None, tile=128):
     # time ~ (rounds of resident workgroups) x (K-iterations per workgroup + fill/epilogue): a split that leaves the last
     # round nearly empty (e.g. 576 workgroups on 512 slots) costs a whole extra round, so search instead of doubling
     best, best_cost = 1, None
-    for s in range(1, min(32, ksteps // 4) + 1):
+    for s in range(1, min(128, ksteps // 4) + 1):
         rounds = -(-tiles * s // slots)
         cost = rounds * (-(-ksteps // s) + 8)
         if best_cost is None or cost < best_cost:
