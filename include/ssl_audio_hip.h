@@ -77,6 +77,10 @@ int sa_set_cu_budget(int32_t cus);
 
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
 int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[c][r] = src[r][c], bf16 [R][C] -> [C][R] (R, C multiples of 8).  The engine keeps a transposed bf16 copy of every Linear weight so that
+ * the data gradients dX = dY W run in the forward (k-contiguous x k-contiguous) operand layout, measured 6-16 % faster than reading W
+ * k-strided; refreshed once per optimiser step. */
+int sa_transpose_bf16(const void* src_bf16, int32_t R, int32_t C, void* dst_bf16, void* stream);
 /* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients); accumulate != 0 adds */
 int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
 

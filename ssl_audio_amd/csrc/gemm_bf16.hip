@@ -457,7 +457,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // raw: the next tile's LDS-DMA stays in flight
     char* wl = smem + cur * BUF + wave * 8192;
-    if constexpr (EPI != 0) {
+    if constexpr (EPI == 4 || EPI == 5) {
+      // (as in the ring kernel) the wave's whole aux_in block is requested before the first store
+      const int nb = n0 + wc * 64;
+      uint4 auxv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + wr * 128 + q * 8 + (lane >> 3);
+        auxv[q] = (m < p.M && nb < p.N) ? *reinterpret_cast<const uint4*>(p.aux_in + (int64_t)m * p.ldaux + nb + (lane & 7) * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, nb, wl, lane, nullptr, nullptr, &auxv[0]);
+      wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, nb, wl, lane, nullptr, nullptr, &auxv[8]);
+    } else if constexpr (EPI != 0) {
       float4 bias4[4];
       const bool has_bias = p.bias != nullptr && n0 + wc * 64 < p.N;
 #pragma unroll
@@ -506,7 +517,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
     return 0;                                                                                                              \
   }
-    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(6) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(5) SA_EPI_CASE(6) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
 #undef SA_EPI_CASE
   }
   hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), 8 * TILE_BYTES, stream, p);
@@ -1052,7 +1063,11 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // k-strided weight) shapes and equal on forward (NT): it is the default for NN only.
   // mode A (phased kernel, gemm_phase.hip): measured faster than mode 6 on the forward layout with the bias + residual -> fp32
   // epilogue (proj 150 vs 163 us, fc2 305 vs 343 us) and equal or slower elsewhere (scripts/bench_gemm.py): default there only.
-  char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : ((a->a_kmajor && p.epi_kind == 3 && a->K >= 2 * BK) ? 'A' : '6')) : '1');
+  // ... and on the plain bias -> bf16 epilogue once the reduction is long (K >= 1536: 266 vs 285 us at K = 3072, 197 vs 211 at 2304; a tie at 768).
+  static const char* k1_env = getenv("SA_GEMM_PHASE_K1");      // experiment knob: minimum K for mode A on epilogue kind 1 (0: never)
+  const int k1_min = k1_env ? atoi(k1_env) : 1536;
+  const bool nt_phase = a->a_kmajor && a->b_kmajor && a->K >= 2 * BK && (p.epi_kind == 3 || (p.epi_kind == 1 && k1_min > 0 && a->K >= k1_min));
+  char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : (nt_phase ? 'A' : '6')) : '1');
   if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     const int rc = sagemm::launch_phase(p, a->a_kmajor, a->b_kmajor, false, stream);
@@ -1106,6 +1121,45 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   }
 }
 }  // namespace
+
+namespace {
+// dst[c][r] = src[r][c] for a bf16 [R][C] matrix: 64 x 64 tiles through LDS (padded rows: no bank conflicts), 16-byte global accesses
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int Cn, bf16_t* __restrict__ dst) {
+  __shared__ bf16_t tile[64][66];
+  const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {                 // 64 rows x 8 chunks of 8 elements
+    const int r = i >> 3, ch = i & 7;
+    bf16x8 v;
+    if (tr + r < R && tc + ch * 8 + 7 < Cn) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)(tr + r) * Cn + tc + ch * 8);
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (tr + r < R && tc + ch * 8 + e < Cn) ? src[(int64_t)(tr + r) * Cn + tc + ch * 8 + e] : f2bf(0.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][ch * 8 + e] = v[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int c = i >> 3, ch = i & 7;                              // output row = source column
+    if (tc + c >= Cn) continue;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[ch * 8 + e][c];
+    bf16_t* o = dst + (int64_t)(tc + c) * R + tr + ch * 8;
+    if (tr + ch * 8 + 7 < R) *reinterpret_cast<bf16x8*>(o) = v;
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (tr + ch * 8 + e < R) o[e] = v[e];
+  }
+}
+}  // namespace
+
+extern "C" int sa_transpose_bf16(const void* src, int32_t R, int32_t Cn, void* dst, void* stream) {
+  SA_CHECK_ARG(src && dst && R > 0 && Cn > 0, "sa_transpose_bf16: bad args");
+  SA_CHECK_ARG(R % 8 == 0 && Cn % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "sa_transpose_bf16: 16-byte aligned rows (R, C multiples of 8)");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cn + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, R, Cn, (bf16_t*)dst);
+  SA_LAUNCH_CHECK("sa_transpose_bf16");
+  return 0;
+}
 
 extern "C" int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   SA_CHECK_ARG(n >= 0 && (n == 0 || (src && dst)), "sa_cast_f32_to_bf16: bad args");

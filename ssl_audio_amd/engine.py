@@ -13,6 +13,7 @@ C-ABI launches per transformer block with fused epilogues and a hand-planned set
 Residual stream fp32, GEMM operands / attention bf16, accumulation fp32.  `torch` only provides device
 memory here.  The autograd.Function at the bottom exposes the schedule to nn.Module callers.
 """
+import os
 import weakref
 
 import torch
@@ -63,6 +64,41 @@ class _Bf16Cache:
 
 
 BF16_WEIGHTS = _Bf16Cache()
+
+# Bumped by whoever rewrites parameters with a HIP kernel (train.FlatState's optimiser step): the pinned bf16 copies are refreshed by
+# that kernel itself, anything DERIVED from them (the transposed copies below) is rebuilt on its next use.
+WEIGHT_EPOCH = [0]
+
+
+class _Bf16TransposedCache:
+    """[in, out] bf16 copies of the [out, in] Linear weights.  The data gradient dX = dY W then reads W^T k-contiguous, i.e. runs in
+    the forward operand layout (NT) instead of through the transposing LDS reads of the k-strided layout (NN): measured 6-16 % faster on
+    the ViT-B shapes (fc2 dgrad 367 -> 312 us), for one transpose of the weights per optimiser step (170 MB of traffic, < 0.1 ms)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p):
+        w16 = BF16_WEIGHTS.get(p)                    # current [out, in] copy (casts if the master changed)
+        key = id(p)
+        ver = (p._version, BF16_WEIGHTS._manual.get(key, 0), WEIGHT_EPOCH[0], w16.data_ptr())
+        ent = self._c.get(key)
+        if ent is None or ent[2]() is not p or ent[0] != ver:
+            buf = ent[1] if ent is not None and ent[2]() is p and ent[1].shape == (w16.shape[1], w16.shape[0]) and ent[1].device == w16.device else None
+            ent = (ver, ops.transpose_bf16(w16.contiguous(), buf), weakref.ref(p))
+            self._c[key] = ent
+        return ent[1]
+
+
+BF16_WEIGHTS_T = _Bf16TransposedCache()
+DGRAD_NT = os.environ.get("SA_DGRAD_NT", "1") != "0"      # data gradients against the transposed weight copies (0: k-strided weights, NN)
+
+
+def _dgrad_w(w):
+    """(B operand, b_kmajor) of a data-gradient GEMM dX = dY W for the Linear weight w [out, in]."""
+    if DGRAD_NT and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+        return BF16_WEIGHTS_T.get(w), True
+    return BF16_WEIGHTS.get(w), False
 
 # id(parameter) -> fp32 buffer (normally a view into train.FlatState's flat gradient buffer).  When a parameter has a
 # sink, the backward kernels accumulate straight into it and autograd is handed None (no per-parameter allocation,
@@ -177,13 +213,15 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
         ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
     fuse_b1 = pre.shape[1] % 64 == 0                  # fc1's bias gradient = column sums of dpre: taken in the epilogue that produces it
-    ops.gemm(dx3_16, W(p.w2), b_kmajor=False, act=4 if _ACT_PAIR else 2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
+    w2b, w2k = _dgrad_w(p.w2)
+    ops.gemm(dx3_16, w2b, b_kmajor=w2k, act=4 if _ACT_PAIR else 2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
     # fc1
     _wgrad(dpre, h2, g.w1)
     if not fuse_b1:
         ops.colsum_bf16(dpre, g.b1, accumulate=True)
     dh2 = torch.empty(M, d, dtype=BF16, device=dev)
-    ops.gemm(dpre, W(p.w1), b_kmajor=False, out_bf16=dh2)
+    w1b, w1k = _dgrad_w(p.w1)
+    ops.gemm(dpre, w1b, b_kmajor=w1k, out_bf16=dh2)
     del dpre
     # LN2 + residual
     dx2 = torch.empty(M, d, device=dev)
@@ -192,7 +230,8 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     # proj
     _wgrad(dx2_16, ao, g.wp)
     dao = dh2  # reuse
-    ops.gemm(dx2_16, W(p.wp), b_kmajor=False, out_bf16=dao)
+    wpb, wpk = _dgrad_w(p.wp)
+    ops.gemm(dx2_16, wpb, b_kmajor=wpk, out_bf16=dao)
     # attention
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv)
@@ -201,7 +240,8 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
     ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
     dh1 = dao
-    ops.gemm(dqkv, W(p.wqkv), b_kmajor=False, out_bf16=dh1)
+    wqb, wqk = _dgrad_w(p.wqkv)
+    ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)
     del dqkv
     # LN1 + residual
     dx = torch.empty(M, d, device=dev)
@@ -276,7 +316,8 @@ def block_backward_cls(dx3, dx3_16, p, g, H, N, saved, prev_b2=None):
     ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
     ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
     dh1 = dao
-    ops.gemm(dqkv, W(p.wqkv), b_kmajor=False, out_bf16=dh1)
+    wqb, wqk = _dgrad_w(p.wqkv)
+    ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)
     del dqkv
     dx = torch.empty(M, d, device=dev)
     dx_16 = torch.empty(M, d, dtype=BF16, device=dev)

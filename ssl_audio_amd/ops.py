@@ -167,6 +167,17 @@ def pick_split_k(M, N, K, cu_count=None, tile=128):
     return best
 
 
+def transpose_bf16(src, dst=None):
+    """dst [C, R] = src [R, C]^T (bf16): the k-contiguous copy of a Linear weight for its data-gradient GEMM."""
+    R, Cn = _req(src, BF16, "src").shape
+    if not src.is_contiguous():
+        raise ValueError("transpose_bf16: src must be contiguous")
+    if dst is None:
+        dst = torch.empty(Cn, R, dtype=BF16, device=src.device)
+    check(lib().sa_transpose_bf16(_p(src), R, Cn, _p(_req(dst, BF16, "dst")), _stream()), "sa_transpose_bf16")
+    return dst
+
+
 def cast_bf16(src, dst=None):
     _req(src, F32, "src")
     src = src.contiguous()

@@ -106,12 +106,14 @@ class FlatState:
         if nt > nd:
             ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr, betas[0], betas[1], eps, 0.0,
                            self.step_count, grad_scale, self.params_bf16[nd:nt])
+        engine.WEIGHT_EPOCH[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
 
     def ema_from(self, other, beta):
         """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch."""
         assert self.params.numel() == other.params.numel()
         ops.ema_update(self.params, other.params, beta)
         ops.cast_bf16(self.params, self.params_bf16)
+        engine.WEIGHT_EPOCH[0] += 1
 
 
 class GradSync:

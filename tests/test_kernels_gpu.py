@@ -524,3 +524,23 @@ def test_mae_recon_loss(dev, B, F, T, row0):
     dpred = torch.full_like(pd, float("nan"))
     ops.mae_recon_loss_bwd(pd, row0, imgs.to(dev), mask.to(dev), ph, pw, acc2, torch.tensor([3.0], device=dev), dpred)
     assert rel_err(dpred, pred_full.grad.double()) < 1e-5
+
+
+def test_transpose_bf16_and_nt_dgrad(dev):
+    """sa_transpose_bf16 (bit-exact, ragged 64-tiles) and the data gradient through the transposed copy: dX = dY W read as NT against W^T is
+    bit-identical to the k-strided NN read of W (same products, same fp32 accumulation order per tile), incl. the fused GELU' / column sums."""
+    g = torch.Generator().manual_seed(3)
+    for R, C in [(768, 2304), (3072, 768), (200, 72), (8, 8), (136, 1000)]:
+        a = bf(torch.randn(R, C, generator=g)).to(torch.bfloat16).to(dev)
+        assert torch.equal(ops.transpose_bf16(a), a.t().contiguous()), (R, C)
+    M, N, K = 3000, 512, 320
+    dY = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev)
+    W = bf(torch.randn(K, N, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    aux = bf(torch.randn(M, N, generator=g)).to(torch.bfloat16).to(dev)
+    o1, o2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    c1, c2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    ops.gemm(dY, W, b_kmajor=False, act=4, aux_in=aux, out_bf16=o1, colsum_out=c1)
+    ops.gemm(dY, ops.transpose_bf16(W), b_kmajor=True, act=4, aux_in=aux, out_bf16=o2, colsum_out=c2)
+    ref = (dY.double().cpu() @ W.double().cpu()) * aux.double().cpu()
+    assert rel_err(o2, ref) < 6e-3 and rel_err(c2, ref.sum(0)) < 2e-3
+    assert rel_err(o1, o2.double().cpu()) < 1e-6 and rel_err(c1, c2.double().cpu()) < 1e-5
