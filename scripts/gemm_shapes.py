@@ -39,5 +39,5 @@ tot = sum(v[1] for v in agg.values())
 print(f"{len(log)} launches, {tot/1e3:.2f} ms")
 for key, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     M, N, K, lay, split, t256, act, epi, out = key
-    fam = ops.gemm_kernel_family(M, N, K, lay[0] == "N", lay[1] == "T", split, t256, False)
+    fam = ops.gemm_kernel_family(M, N, K, lay[0] == "N", lay[1] == "T", split, t256, out == "f32" and "residual" in epi and act == 0, out == "bf16" and act == 0 and "aux" not in epi)
     print(f"{lay} M={M:6d} N={N:5d} K={K:6d} split={split:2d}{'*' if t256 else ' '} act={act} {epi:28s} {out:4s} x{n:3d}  {t/n:8.1f} us  {2*M*N*K/(t/n)/1e6:7.1f} TF/s  {100*t/tot:5.1f}%  {fam}")

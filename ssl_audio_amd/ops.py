@@ -103,7 +103,9 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     kind = ("NT" if b_kmajor else "NN") if a_kmajor else ("TT" if b_kmajor else "TN")
     epi3 = (residual is not None and not res_mod and not row_group and out_f32 is not None and out_bf16 is None and act == 0 and aux_in is None
             and aux_out is None and colsum_out is None and not accumulate and N % 64 == 0)
-    kname = gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3)
+    epi1 = (out_bf16 is not None and out_f32 is None and residual is None and act == 0 and aux_in is None and aux_out is None and colsum_out is None
+            and not accumulate and not row_group and N % 64 == 0)
+    kname = gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3, epi1)
     nbytes = 2.0 * (M * K + N * K) + (4.0 * M * N if out_f32 is not None else 0.0) + (2.0 * M * N if out_bf16 is not None else 0.0) \
         + (2.0 * M * N if (aux_in is not None or aux_out is not None) else 0.0) + (4.0 * M * N if residual is not None and not res_mod else 0.0)
     GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, kind + ("/splitk" if split_k > 1 else ""), nbytes, kname))
@@ -133,10 +135,11 @@ def set_cu_budget(cus):
     CU_BUDGET = int(cus) if cus else None
 
 
-def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False):
+def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False, epi1=False):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
     override); used to label bench.py's per-launch timings with the names rocprofv3 reports.  epi3: the launch has the compact
-    bias + residual -> fp32 epilogue (proj / fc2 forward), which the forward layout runs on the phased kernel."""
+    bias + residual -> fp32 epilogue (proj / fc2 forward), which the forward layout runs on the phased kernel; epi1: the compact
+    (bias ->) bf16 epilogue, phased too once the reduction is long (K >= 1536: the fc1 / qkv data gradients)."""
     if split_k > 1:
         return "gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>"
     big = M >= 1024 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
@@ -144,7 +147,8 @@ def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False
         return "gemm_kernel"
     if a_kmajor and not b_kmajor:
         return "gemm256_ring_kernel"
-    return "gemm256_phase_kernel" if (a_kmajor and b_kmajor and epi3 and K >= 128) else "gemm256_persist_kernel"
+    phased = a_kmajor and b_kmajor and K >= 128 and (epi3 or (epi1 and K >= 1536))
+    return "gemm256_phase_kernel" if phased else "gemm256_persist_kernel"
 
 
 def pick_split_k(M, N, K, cu_count=None, tile=128):

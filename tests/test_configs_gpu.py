@@ -79,6 +79,8 @@ def test_cfg3_vit_base_10s_step_vs_oracle(dev):
     M = 2 * B * 249
     for (n, k) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
         assert ops.gemm_kernel_family(M, n, k, True, True, 1, False) == "gemm256_persist_kernel"
+        # data gradients read the transposed weight copy in the forward layout (engine._dgrad_w); the k-strided read stays available
+        assert ops.gemm_kernel_family(M, k, n, True, True, 1, False, epi1=True) in ("gemm256_persist_kernel", "gemm256_phase_kernel")
         assert ops.gemm_kernel_family(M, k, n, True, False, 1, False) == "gemm256_ring_kernel"
     sd0 = cpu_state(tr.online)
     views = correlated_views(B, T, seed=11)
