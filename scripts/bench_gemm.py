@@ -17,15 +17,19 @@ res = rf(M, d)
 W = {"qkv": rb(3 * d, d) * 0.05, "proj": rb(d, d) * 0.05, "fc1": rb(4 * d, d) * 0.05, "fc2": rb(d, 4 * d) * 0.05}
 bias = {"qkv": rf(3 * d), "proj": rf(d), "fc1": rf(4 * d), "fc2": rf(d)}
 aux = rb(M, 4 * d)
+NT = os.environ.get("SA_DGRAD_NT", "1") != "0"
+DG = "NT" if NT else "NN"
+WD = {k: (ops.transpose_bf16(v.contiguous()) if NT else v) for k, v in W.items()}
 cases = [
     ("fwd  NT qkv  bias->bf16", lambda o=e16(M, 3 * d): ops.gemm(x16, W["qkv"], bias=bias["qkv"], out_bf16=o), 2.0 * M * 3 * d * d),
     ("fwd  NT proj bias+res->f32", lambda o=torch.empty(M, d, device=dev): ops.gemm(x16, W["proj"], bias=bias["proj"], residual=res, out_f32=o), 2.0 * M * d * d),
     ("fwd  NT fc1  gelu pair", lambda o=e16(M, 4 * d), a=e16(M, 4 * d): ops.gemm(x16, W["fc1"], bias=bias["fc1"], act=3, aux_out=a, out_bf16=o), 2.0 * M * 4 * d * d),
     ("fwd  NT fc2  bias+res->f32", lambda o=torch.empty(M, d, device=dev): ops.gemm(h4, W["fc2"], bias=bias["fc2"], residual=res, out_f32=o), 2.0 * M * 4 * d * d),
-    ("dgrad NN fc2 *gelu' +colsum", lambda o=e16(M, 4 * d), cs=torch.zeros(4 * d, device=dev): ops.gemm(x16, W["fc2"], b_kmajor=False, act=4, aux_in=aux, out_bf16=o, colsum_out=cs), 2.0 * M * 4 * d * d),
-    ("dgrad NN fc1 ->bf16", lambda o=e16(M, d): ops.gemm(h4, W["fc1"], b_kmajor=False, out_bf16=o), 2.0 * M * 4 * d * d),
-    ("dgrad NN proj ->bf16", lambda o=e16(M, d): ops.gemm(x16, W["proj"], b_kmajor=False, out_bf16=o), 2.0 * M * d * d),
-    ("dgrad NN qkv ->bf16", lambda o=e16(M, d): ops.gemm(q16, W["qkv"], b_kmajor=False, out_bf16=o), 2.0 * M * 3 * d * d),
+    # data gradients as the engine runs them: against the transposed bf16 weight copy, forward operand layout (SA_DGRAD_NT=0 / "NN" below: k-strided W)
+    ("dgrad %s fc2 *gelu' +colsum" % DG, lambda o=e16(M, 4 * d), cs=torch.zeros(4 * d, device=dev): ops.gemm(x16, WD["fc2"], b_kmajor=NT, act=4, aux_in=aux, out_bf16=o, colsum_out=cs), 2.0 * M * 4 * d * d),
+    ("dgrad %s fc1 ->bf16" % DG, lambda o=e16(M, d): ops.gemm(h4, WD["fc1"], b_kmajor=NT, out_bf16=o), 2.0 * M * 4 * d * d),
+    ("dgrad %s proj ->bf16" % DG, lambda o=e16(M, d): ops.gemm(x16, WD["proj"], b_kmajor=NT, out_bf16=o), 2.0 * M * d * d),
+    ("dgrad %s qkv ->bf16" % DG, lambda o=e16(M, d): ops.gemm(q16, WD["qkv"], b_kmajor=NT, out_bf16=o), 2.0 * M * 3 * d * d),
 ]
 for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16), ("fc1", 4 * d, d, h4, x16), ("fc2", d, 4 * d, x16, h4)]:
     out = torch.zeros(N, K, device=dev)
