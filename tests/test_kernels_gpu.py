@@ -544,3 +544,50 @@ def test_transpose_bf16_and_nt_dgrad(dev):
     ref = (dY.double().cpu() @ W.double().cpu()) * aux.double().cpu()
     assert rel_err(o2, ref) < 6e-3 and rel_err(c2, ref.sum(0)) < 2e-3
     assert rel_err(o1, o2.double().cpu()) < 1e-6 and rel_err(c1, c2.double().cpu()) < 1e-5
+
+
+def test_c_abi_launches_are_graph_capturable(dev):
+    """include/ssl_audio_hip.h promises that no entry point allocates, frees or synchronises: a GEMM (fused epilogue + column sums through
+    the cached workspace), a LayerNorm, the fused attention and a split-K weight gradient are captured into ONE HIP graph and replayed on
+    new inputs; the replay must equal the eager launches bit for bit (the split-K sum in slice order)."""
+    g = torch.Generator().manual_seed(9)
+    M, d, H, N = 4 * 64, 128, 2, 64
+    x = torch.randn(M, d, generator=g).to(dev)
+    w = bf(torch.randn(3 * d, d, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    h16 = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    qkv = torch.empty(M, 3 * d, dtype=torch.bfloat16, device=dev)
+    ao = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(M // N * H, N, device=dev)
+    dw = torch.zeros(3 * d, d, device=dev)
+    bias = torch.randn(3 * d, generator=g).to(dev)
+
+    def launches():
+        ops.layernorm_fwd(x, gamma, beta, 1e-6, y_bf16=h16, mean=mean, rstd=rstd)
+        ops.gemm(h16, w, bias=bias, out_bf16=qkv)
+        ops.attention_fwd(qkv, H, N, 0.125, ao, lse)
+        dw.zero_()
+        ops.gemm(qkv, h16, a_kmajor=False, b_kmajor=False, out_f32=dw, split_k=2)
+
+    old = ops.DETERMINISTIC_WGRAD
+    ops.DETERMINISTIC_WGRAD = True
+    try:
+        launches()                                   # warm-up: workspaces, function attributes
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                launches()
+        x.copy_(torch.randn(M, d, generator=g))      # new input, same buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (h16, qkv, ao, lse, dw)]
+        launches()
+        torch.cuda.synchronize()
+        for a, b in zip(got, (h16, qkv, ao, lse, dw)):
+            assert torch.equal(a, b)
+        assert float(dw.abs().sum()) > 0
+    finally:
+        ops.DETERMINISTIC_WGRAD = old
