@@ -204,8 +204,10 @@ def layernorm_fwd(x, gamma, beta, eps, *, y_bf16=None, y_f32=None, mean=None, rs
     ldy = _rows(y, "y")[2]
     if y_bf16 is not None and y_f32 is not None and _rows(y_f32, "y_f32")[2] != ldy:
         raise ValueError("layernorm_fwd: both outputs must share a leading dimension")
-    check(lib().sa_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), ldy, _p(mean), _p(rstd), M, D, float(eps),
-                                 _stream()), "sa_layernorm_fwd")
+    # algorithmic bytes: x read once (4 B), each output written once
+    _timed("ln_fwd_kernel", float(M) * D * (4 + (2 if y_bf16 is not None else 0) + (4 if y_f32 is not None else 0)), lambda: check(
+        lib().sa_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), ldy, _p(mean), _p(rstd), M, D, float(eps), _stream()),
+        "sa_layernorm_fwd"))
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None, dxsum=None):
@@ -217,8 +219,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=N
     ws = None
     if dgamma is not None or dbeta is not None or dxsum is not None:      # scratch for the two-stage column reduction
         ws = _workspace(lib().sa_layernorm_bwd_workspace_bytes(M, D), x.device, "ln_bwd")
-    check(lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
-                                 _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), _p(ws), M, D, _stream()), "sa_layernorm_bwd")
+    nbytes = float(M) * D * (4 + (2 if dy.dtype == BF16 else 4) + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_bf16 is not None else 0))
+    _timed("ln_bwd_kernel", nbytes, lambda: check(
+        lib().sa_layernorm_bwd(_p(dy), int(dy.dtype == BF16), lddy, _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), lddres,
+                               _p(dx_f32), _p(dx_bf16), lddx, _p(dgamma), _p(dbeta), _p(dxsum), _p(ws), M, D, _stream()), "sa_layernorm_bwd"))
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -297,8 +301,10 @@ def bt_loss_grad(c, alpha, lmbda, hsic, loss, G=None):
 # ------------------------------------------------------------------------------------------------ optimiser
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None):
     n = p.numel()
-    check(lib().sa_adamw_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
-                              float(grad_scale), _p(p_bf16), _stream()), "sa_adamw_step")
+    # algorithmic bytes per parameter: p, g, m, v read (16 B), p, m, v written (12 B), bf16 copy written (2 B)
+    _timed("adamw_vec4_kernel", float(n) * (28 + (2 if p_bf16 is not None else 0)), lambda: check(
+        lib().sa_adamw_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                            float(grad_scale), _p(p_bf16), _stream()), "sa_adamw_step"))
 
 
 def lars_step(p, g, mu, lr, wd, momentum, eta, adapt, scratch2=None, p_bf16=None):
