@@ -96,7 +96,8 @@ DGRAD_NT = os.environ.get("SA_DGRAD_NT", "1") != "0"      # data gradients again
 
 def _dgrad_w(w):
     """(B operand, b_kmajor) of a data-gradient GEMM dX = dY W for the Linear weight w [out, in]."""
-    if DGRAD_NT and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+    # (a k-contiguous operand needs the reduction length -- here out_features -- to be a multiple of the 64-wide K-tile)
+    if DGRAD_NT and w.shape[0] % 64 == 0 and w.shape[1] % 8 == 0:
         return BF16_WEIGHTS_T.get(w), True
     return BF16_WEIGHTS.get(w), False
 
