@@ -14,10 +14,10 @@ from ._lib import SaGemmArgs, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-# Weight gradients are split-K sums.  By default the K slices add into the gradient buffer with fp32 atomics (fastest; exact up to the
-# rounding of an arbitrary summation order, so not bit-reproducible from run to run); with DETERMINISTIC_WGRAD (or SA_DETERMINISTIC=1)
-# every slice stores its partial tile in a workspace and a second launch adds the slices in slice order.
-DETERMINISTIC_WGRAD = os.environ.get("SA_DETERMINISTIC", "0") == "1"
+# Weight gradients are split-K sums.  By default every K slice stores its partial tile in a workspace and a second launch adds the slices
+# in slice order: bit-reproducible from run to run, and measured 2 % FASTER than fp32 atomics on the ViT-B shapes (266 vs 273 us on the qkv
+# weight gradient: 16 M four-byte atomics cost more than writing and re-reading 64 MB).  SA_DETERMINISTIC=0 selects the atomic form.
+DETERMINISTIC_WGRAD = os.environ.get("SA_DETERMINISTIC", "1") != "0"
 GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end event, flops, layout) per GEMM launch
 STREAM_PROFILE = None  # set to a dict by bench.py: kernel name -> [(start event, end event, algorithmic bytes)] for the HBM-bound front kernels
 
