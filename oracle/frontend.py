@@ -56,12 +56,16 @@ def power_spectrogram(wave, n_fft=1024, hop=160, dtype=np.float64, win_length=No
     return np.swapaxes(p, -1, -2)
 
 
-def logmel(wave, n_fft=1024, hop=160, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, dtype=np.float64, win_length=None):
-    """wave [..., L] -> log-mel [..., n_mels, frames]  (datasets.py:39-48,115)."""
+def mel_power(wave, n_fft=1024, hop=160, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, dtype=np.float64, win_length=None):
+    """wave [..., L] -> mel power spectrogram [..., n_mels, frames]: what `MelSpectrogram(..., power=2)` returns (datasets.py:39-48)."""
     p = power_spectrogram(wave, n_fft, hop, dtype, win_length)
     fb = mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate).astype(dtype)
-    mel = np.einsum("...ft,fm->...mt", p, fb)
-    return np.log(mel + EPS32)
+    return np.einsum("...ft,fm->...mt", p, fb)
+
+
+def logmel(wave, n_fft=1024, hop=160, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, dtype=np.float64, win_length=None):
+    """wave [..., L] -> log-mel [..., n_mels, frames]  (datasets.py:39-48,115)."""
+    return np.log(mel_power(wave, n_fft, hop, n_mels, f_min, f_max, sample_rate, dtype, win_length) + EPS32)
 
 
 def crop_pad_normalize(lms, crop_frames, start, mean, std):

@@ -1,6 +1,8 @@
 """HEAR wrapper oracle (TEST INFRASTRUCTURE): restates hear/sample/vit.py:88-126,160-247 and hear/utils.py:36-106 with the oracle's
-own frontend and encoder.  The mel arithmetic is torchaudio's in the reference (absent here): like oracle/frontend.py this part is
-parity UNPINNED; framing, normalisation statistics, unit chunking and averaging are restated from the reference's own code."""
+own frontend and encoder.  The mel arithmetic is torchaudio's in the reference (absent here): like oracle/frontend.py that part is
+parity UNPINNED.  Everything around it -- log + eps, normalisation statistics, framing, unit chunking, averaging, timestamps -- is
+pinned by tests/test_oracle_golden.py against tests/golden/hear.npz, produced by running the reference's wrapper with that one
+class stood in for (tests/golden/make_golden.py::gen_hear)."""
 import numpy as np
 import torch
 

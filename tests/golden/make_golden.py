@@ -645,7 +645,66 @@ def gen_resnet():
     save("resnet", **out)
 
 
+def gen_hear():
+    """HEAR wrapper (hear/sample/vit.py:40-247, hear/utils.py) run as the reference runs it: `ViTModelWrapper` + `get_scene_embeddings` /
+    `get_timestamp_embeddings` on two 1.3 s clips.  Two absent third-party names are stood in for: `easydict.EasyDict` (attribute dict)
+    and `torchaudio.transforms.MelSpectrogram` -- the latter by oracle/frontend.py's restatement of torchaudio's documented defaults, so
+    this fixture pins everything the wrapper does AROUND the mel spectrogram (log + eps, batch statistics incl. compute_timestamp_stats'
+    division by the frame count, framing, unit chunking with the extra padded unit, CLS pooling, timestamps) and leaves the mel
+    arithmetic itself unpinned, as DESIGN.md section 3 states.  The encoder is the micro ViT of the other fixtures, injected through
+    `mae.get_mae_vit` (the wrapper's logic does not depend on the encoder's size)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import frontend as ofe
+
+    class EasyDict(dict):
+        __getattr__ = dict.__getitem__
+
+    class MelSpectrogram(nn.Module):
+        def __init__(self, sample_rate, n_fft, win_length, hop_length, n_mels, f_min, f_max, power=2):
+            super().__init__()
+            assert power == 2
+            self.kw = dict(n_fft=n_fft, hop=hop_length, n_mels=n_mels, f_min=float(f_min), f_max=float(f_max), sr=sample_rate, win=win_length)
+
+        def forward(self, wave):
+            k = self.kw
+            mel = ofe.mel_power(wave.detach().cpu().double().numpy(), k["n_fft"], k["hop"], k["n_mels"], k["f_min"], k["f_max"], k["sr"], win_length=k["win"])
+            return torch.from_numpy(mel).float()
+
+    ta, tat, ed = types.ModuleType("torchaudio"), types.ModuleType("torchaudio.transforms"), types.ModuleType("easydict")
+    tat.MelSpectrogram, ta.transforms, ed.EasyDict = MelSpectrogram, tat, EasyDict
+    sys.modules.update({"torchaudio": ta, "torchaudio.transforms": tat, "easydict": ed})
+    import importlib
+    ref_hear = importlib.import_module("hear.sample.vit")
+    torch.manual_seed(0)
+    micro = micro_vit()
+    orig = ref_mae.get_mae_vit
+    ref_mae.get_mae_vit = lambda size, patch_size, c: micro
+    try:
+        cwd = os.getcwd()
+        os.chdir(REF)                                   # the wrapper opens hear/config.yaml relative to the repository root
+        model = ref_hear.load_model("", "vit_tiny", "16x16")
+        model = model.cpu()
+        g = torch.Generator().manual_seed(5)
+        t = torch.arange(20800) / 16000.0
+        audio = 0.1 * torch.randn(2, 20800, generator=g) + 0.4 * torch.sin(2 * torch.pi * 440.0 * t)[None] * torch.tensor([[1.0], [0.3]])
+        orig_cuda = torch.cuda.is_available
+        torch.cuda.is_available = lambda: False
+        scene = ref_hear.get_scene_embeddings(audio, model)
+        emb, ts = ref_hear.get_timestamp_embeddings(audio, model, hop_size=100)
+        spec = model._to_normalized_spec(audio)
+        torch.cuda.is_available = orig_cuda
+    finally:
+        ref_mae.get_mae_vit = orig
+        os.chdir(cwd)
+    out = {"audio": t2n(audio), "scene": t2n(scene), "ts_emb": t2n(emb), "ts": t2n(ts), "norm_spec": t2n(spec),
+           "unit_frames": np.array(micro.img_size[1]), "timestamp_embedding_size": np.array(model.timestamp_embedding_size)}
+    for k, v in micro.state_dict().items():
+        out["sd." + k] = t2n(v)
+    save("hear", **out)
+
+
 if __name__ == "__main__":
+    gen_hear() if "hear" in sys.argv[1:] else None
     gen_resnet() if "resnet" in sys.argv[1:] else None
     gen_convstem() if "convstem" in sys.argv[1:] else None
     gen_audiontt() if "audiontt" in sys.argv[1:] else None

@@ -1,6 +1,7 @@
 """HEAR wrappers and checkpoint-key compatibility (hear/sample/vit.py:64-77,129-247, linear.py:114-133)."""
 import os
 import tempfile
+from functools import partial
 
 import numpy as np
 import pytest
@@ -79,3 +80,28 @@ def test_checkpoint_keys_round_trip(dev):
     assert torch.equal(engine.BF16_WEIGHTS.get(p).float(), p.detach().to(torch.bfloat16).float())
     l1, l2 = float(tr1.step_views(views)), float(tr2.step_views(views))   # and a step on the loaded weights runs
     assert np.isfinite(l2) and abs(l1 - l2) <= 1e-5 * abs(l1)
+
+
+def test_hear_wrapper_vs_reference_fixture(dev):
+    """The HEAR wrapper against what the REFERENCE's wrapper produced (tests/golden/hear.npz: hear/sample/vit.py run with the micro ViT and
+    torchaudio's MelSpectrogram stood in for by our restatement): normalised log-mel 1e-3, scene and timestamp embeddings 2e-2 (bf16
+    encoder), timestamps exact."""
+    from ssl_audio_amd import mae
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hear.npz"))
+    model = hvit.load_model("", "vit_tiny", "16x16")
+    micro = mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                     norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), use_decoder=False, decoder_embed_dim=64,
+                                     decoder_depth=1, decoder_num_heads=1).to(dev)
+    micro.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}, strict=True)
+    model.model = micro
+    model.scene_embedding_size = micro.embed_dim
+    model.timestamp_embedding_size = micro.embed_dim * micro.grid_size()[0]
+    assert model.timestamp_embedding_size == int(g["timestamp_embedding_size"])
+    audio = torch.from_numpy(g["audio"]).to(dev)
+    spec = model._to_normalized_spec(audio)
+    assert rel(spec, g["norm_spec"]) < 1e-3, rel(spec, g["norm_spec"])
+    scene = hvit.get_scene_embeddings(audio, model)
+    assert scene.shape == g["scene"].shape and rel(scene, g["scene"]) < 2e-2, rel(scene, g["scene"])
+    emb, ts = hvit.get_timestamp_embeddings(audio, model, hop_size=100)
+    assert emb.shape == g["ts_emb"].shape and np.allclose(ts.cpu().numpy(), g["ts"], atol=1e-3)
+    assert rel(emb, g["ts_emb"]) < 2e-2, rel(emb, g["ts_emb"])

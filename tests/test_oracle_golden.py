@@ -431,3 +431,25 @@ def test_resnet_oracle_matches_reference(golden, variant):
         if key in g:
             assert np.allclose(0.1 * mean.numpy(), g[key], rtol=1e-4, atol=1e-6), name
             assert np.allclose(0.9 + 0.1 * var.numpy() * cnt / (cnt - 1), g[f"{variant}.after.{name}.running_var"], rtol=1e-4, atol=1e-6), name
+
+
+def test_hear_oracle_matches_the_reference_wrapper(golden):
+    """oracle/hear.py == hear/sample/vit.py + hear/utils.py as the reference ran them (tests/golden/hear.npz: the reference's wrapper with
+    `torchaudio.transforms.MelSpectrogram` stood in for by oracle/frontend.py, so the mel arithmetic itself stays unpinned): the normalised
+    log-mel, scene embeddings (mean over units incl. the extra padded unit), timestamp embeddings with compute_timestamp_stats' division
+    by the frame count, and the timestamps."""
+    from oracle import hear as ohear
+    g = golden("hear")
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")}
+    audio = g["audio"]
+    unit = int(g["unit_frames"])
+    x = ohear.to_feature(audio)
+    x = (x - x.mean()) / x.std()
+    np.testing.assert_allclose(x.numpy(), g["norm_spec"], rtol=0, atol=2e-5)
+    scene = ohear.scene_embeddings(audio, sd, 2, (4, 6), unit)
+    assert scene.shape == g["scene"].shape
+    np.testing.assert_allclose(scene.numpy(), g["scene"], rtol=0, atol=2e-4)
+    emb, ts = ohear.timestamp_embeddings(audio, sd, 2, (4, 6), unit, hop_size=100)
+    assert emb.shape == g["ts_emb"].shape and int(g["timestamp_embedding_size"]) == 128 * 4
+    np.testing.assert_allclose(ts, g["ts"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(emb.numpy(), g["ts_emb"], rtol=0, atol=5e-4)
