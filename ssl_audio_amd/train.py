@@ -108,6 +108,53 @@ class FlatState:
                            self.step_count, grad_scale, self.params_bf16[nd:nt])
         engine.WEIGHT_EPOCH[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
 
+    # ------------------------------------------------------------------ checkpoint / resume (main_bt_byol.py:492-503, utils/utils.py:37-46)
+    def _trainable(self):
+        return [(n, p) for n, p in self.order if p.requires_grad]      # decayed first, then un-decayed: utils.get_param_groups' order
+
+    def optim_state_dict(self, lr, wd, betas=(0.9, 0.999), eps=1e-8):
+        """The Adam moments in `torch.optim.AdamW.state_dict()` form over `utils.get_param_groups(model)`'s parameter order, so that the
+        'optimizer' entry of a checkpoint is interchangeable between this flat state and the reference driver's own optimiser."""
+        state, idx = {}, 0
+        groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=wd, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                       differentiable=False, fused=None, params=[]) for _ in range(2)]
+        groups[1]["weight_decay"] = 0.0
+        for n, p in self._trainable():
+            off, cnt = self.offsets[n]
+            state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off:off + cnt].view(p.shape).clone(),
+                          "exp_avg_sq": self.v[off:off + cnt].view(p.shape).clone()}
+            groups[0 if off < self.n_decay else 1]["params"].append(idx)
+            idx += 1
+        return {"state": state, "param_groups": groups}
+
+    def load_optim_state_dict(self, sd):
+        """Inverse of optim_state_dict; accepts what torch.optim.AdamW(utils.get_param_groups(model)).state_dict() wrote."""
+        named = self._trainable()
+        n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_saved != len(named):
+            raise ValueError(f"optimizer state has {n_saved} parameters, the model has {len(named)} trainable ones")
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for i, (n, p) in enumerate(named):
+            st = sd["state"].get(i)
+            if st is None:                                   # a parameter that never received a gradient has no state entry
+                continue
+            off, cnt = self.offsets[n]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {n} has {tuple(p.shape)}")
+            self.m[off:off + cnt].copy_(st["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+            self.v[off:off + cnt].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one count")
+        self.step_count = steps.pop() if steps else 0
+
+    def refresh_from_parameters(self):
+        """After load_state_dict wrote the (flat-backed) parameters: re-cast the bf16 copies the GEMMs read."""
+        ops.cast_bf16(self.params, self.params_bf16)
+        engine.WEIGHT_EPOCH[0] += 1
+
     def ema_from(self, other, beta):
         """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch."""
         assert self.params.numel() == other.params.numel()
@@ -287,6 +334,39 @@ class BarlowTwinsTrainer:
             self.assert_finite()
         return self.last_loss
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self, epoch=0):
+        """The dictionary main_bt_byol.py:492-498 saves ('model', 'optimizer', 'epoch', 'barlow_twins_loss'; the reference's drop of the
+        predictor / target there is SURVEY.md A.5's quirk -- they are included here so that a byol run resumes exactly)."""
+        sd = {"model": self.online.state_dict(), "optimizer": self.flat.optim_state_dict(self.lr, self.wd), "epoch": epoch,
+              "barlow_twins_loss": self.criterion.state_dict(), "steps": self._steps}
+        if self.mode == "byol":
+            sd["predictor"] = self.predictor.state_dict()
+            sd["optimizer_predictor"] = self.flat_pred.optim_state_dict(self.lr, self.wd)
+            sd["target"] = self.target.state_dict()
+        return sd
+
+    def load_state_dict(self, ckpt):
+        """Resume from state_dict()'s dictionary, or from a checkpoint of the reference driver (utils/utils.py:37-46: 'model', 'optimizer'
+        [, 'predictor'], 'epoch'; DDP's 'module.' prefix accepted).  Returns the epoch to continue with."""
+        strip = lambda sd: {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.online.load_state_dict(strip(ckpt["model"]))
+        self.flat.refresh_from_parameters()
+        if "optimizer" in ckpt:
+            self.flat.load_optim_state_dict(ckpt["optimizer"])
+        if "barlow_twins_loss" in ckpt:
+            self.criterion.load_state_dict(ckpt["barlow_twins_loss"])
+        if self.mode == "byol":
+            if "predictor" in ckpt:
+                self.predictor.load_state_dict(strip(ckpt["predictor"]))
+                self.flat_pred.refresh_from_parameters()
+            if "optimizer_predictor" in ckpt:
+                self.flat_pred.load_optim_state_dict(ckpt["optimizer_predictor"])
+            self.target.load_state_dict(strip(ckpt["target"]) if "target" in ckpt else self.online.state_dict())
+            self.flat_target.refresh_from_parameters()
+        self._steps = int(ckpt.get("steps", 0))
+        return int(ckpt.get("epoch", 0))
+
     def assert_finite(self):
         """Raises FloatingPointError if any step since the last call produced a non-finite loss (one host read of the device flag)."""
         bad = int(self._nonfinite.item())
@@ -314,6 +394,7 @@ class _FrozenFlat:
         ops.cast_bf16(self.params, self.params_bf16)
 
     ema_from = FlatState.ema_from
+    refresh_from_parameters = FlatState.refresh_from_parameters
 
 
 def _feature_dim(cfg):

@@ -96,6 +96,15 @@ def model_setup_ddp(gpu, model):
     return wrapped, wrapped.module
 
 
+def load_checkpoint(ckpt_path, model, predictor, optimizer):
+    """utils/utils.py:37-46 (`main.py --resume_path`): model, predictor and optimizer state from a checkpoint; returns the epoch to resume at."""
+    ckpt = torch.load(ckpt_path, map_location=torch.device('cpu'))
+    model.load_state_dict(ckpt['model'])
+    predictor.load_state_dict(ckpt['predictor'])
+    optimizer.load_state_dict(ckpt['optimizer'])
+    return ckpt['epoch']
+
+
 def save_on_master(*args, **kwargs):
     if is_main_process():
         torch.save(*args, **kwargs)

@@ -105,3 +105,37 @@ def test_hear_wrapper_vs_reference_fixture(dev):
     emb, ts = hvit.get_timestamp_embeddings(audio, model, hop_size=100)
     assert emb.shape == g["ts_emb"].shape and np.allclose(ts.cpu().numpy(), g["ts"], atol=1e-3)
     assert rel(emb, g["ts_emb"]) < 2e-2, rel(emb, g["ts_emb"])
+
+
+@pytest.mark.parametrize("mode", ["bt", "byol"])
+def test_trainer_checkpoint_resume(dev, mode):
+    """save -> load -> continue (main_bt_byol.py:492-503, utils/utils.py:37-46): a trainer that loads state_dict() of another after two steps
+    takes the same third step (loss and weights; the fused AdamW's moments and step count travel in torch.optim.AdamW's state_dict form),
+    and that 'optimizer' entry loads into the reference driver's own torch.optim.AdamW over utils.get_param_groups."""
+    from ssl_audio_amd import utils
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       stop_gradient=(mode == "byol"), predictor=(mode == "byol"))
+    g = torch.Generator().manual_seed(4)
+    batches = [[torch.randn(8, 1, 64, 96, generator=g).to(dev), torch.randn(8, 1, 64, 96, generator=g).to(dev)] for _ in range(3)]
+    a = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
+    for v in batches[:2]:
+        a.step_views(v)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ckpt.pth")
+        utils.save_on_master(a.state_dict(epoch=3), path)
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    b = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=9, from_waveform=False)
+    assert b.load_state_dict(ckpt) == 3 and b.flat.step_count == 2
+    assert torch.equal(a.flat.params, b.flat.params) and torch.equal(a.flat.m, b.flat.m) and torch.equal(a.flat.v, b.flat.v)
+    assert torch.equal(a.flat.params_bf16, b.flat.params_bf16)
+    la, lb = float(a.step_views(batches[2])), float(b.step_views(batches[2]))
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    assert rel(b.flat.params, a.flat.params.cpu()) < 1e-6
+    # the optimizer entry in the reference driver's optimiser
+    opt = torch.optim.AdamW(utils.get_param_groups(b.online), lr=cfg.lr, weight_decay=cfg.wd)
+    opt.load_state_dict(ckpt["optimizer"])
+    p0 = opt.param_groups[0]["params"][0]
+    name0 = [n for n, p in b.online.named_parameters() if p is p0][0]
+    off, cnt = a.flat.offsets[name0]
+    assert opt.state[p0]["exp_avg"].shape == p0.shape and int(float(opt.state[p0]["step"])) == 2
+    assert len(opt.param_groups) == 2 and opt.param_groups[1]["weight_decay"] == 0.0
