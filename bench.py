@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--workload", default="vit_base_bt_10s", choices=sorted(WORKLOADS))
     ap.add_argument("--batch_per_gpu", type=int, default=None)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graph", action="store_true", help="run every step eagerly (default: the device part of the step is one HIP graph)")
+    ap.add_argument("--profile_steps", type=int, default=3, help="eager steps with per-launch HIP events after the timed region (roofline)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator comes up, so
@@ -185,27 +187,58 @@ def main():
         torch.cuda.synchronize()
 
     note(f"model + {2 * B} synthetic clips resident; warm-up x{args.warmup}")
-    for i in range(args.warmup):
+    use_graph = not args.no_graph and mode != "mae" and os.environ.get("SA_BENCH_GRAPH", "1") != "0"
+    for i in range(max(args.warmup, 1)):
         trainer.step(pool[i % 2])
         torch.cuda.synchronize()
         note(f"warm-up step {i} done (loss {float(trainer.last_loss):.4f})")
+        if i == 0 and use_graph:
+            # the device part of the step (forward, loss, backward, all-reduce, AdamW) becomes ONE HIP graph; the remaining warm-up steps
+            # replay it.  A failed capture is fatal for this process (no silent eager fallback): rank 0 of a single-GPU run hands over
+            # to a FRESH child process that runs eagerly (never a re-exec of a process that has touched the GPU).
+            try:
+                trainer.enable_graph()
+                trainer.step(pool[1])                                  # first replay (untimed)
+                torch.cuda.synchronize()
+                note("device step captured into a HIP graph")
+            except Exception as e:  # noqa: BLE001
+                note(f"HIP graph capture FAILED: {e!r}")
+                if world > 1:
+                    raise
+                import subprocess
+                os.dup2(real_stdout, 1)
+                child = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no_graph"])
+                sys.exit(child.returncode)
     barrier()
-    ops.GEMM_PROFILE = []                                          # HIP events around every GEMM launch of the timed region
-    ops.STREAM_PROFILE = {}                                        # ... and around the HBM-bound frontend / augmentation launches
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.step(pool[i % 2])
     barrier()
     dt = time.perf_counter() - t0
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    sprof, ops.STREAM_PROFILE = ops.STREAM_PROFILE, None
     trainer.assert_finite()                                        # the step's device-side finite-loss counter, read once here
     note(f"timed region done: {args.steps} steps in {dt:.3f}s")
+    loss_val = float(loss)
+    # roofline pass, OUTSIDE the timed region: a few eager steps of the same workload with HIP events (on the launch stream) around every
+    # GEMM launch and around the HBM-bound frontend / augmentation / LayerNorm / AdamW launches
+    psteps = max(args.profile_steps, 1)
+    trainer.use_graph = False
+    trainer.step(pool[0])                                          # (re-warms the eager allocator paths)
+    barrier()
+    ops.GEMM_PROFILE = []
+    ops.STREAM_PROFILE = {}
+    tp0 = time.perf_counter()
+    for i in range(psteps):
+        trainer.step(pool[i % 2])
+    barrier()
+    dtp = time.perf_counter() - tp0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    sprof, ops.STREAM_PROFILE = ops.STREAM_PROFILE, None
+    trainer.use_graph = True
+    note(f"profiled pass done: {psteps} eager steps in {dtp:.3f}s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    loss_val = float(loss)
 
     if rank == 0:
         clips_per_s = B * world * args.steps / dt
@@ -246,7 +279,7 @@ def main():
                 gbs = nb / (ms * 1e-3) / 1e9
                 hbm_kernels[kname] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                       "launches": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
-                                      "algorithmic_bytes_per_launch": round(nb / len(recs)), "share_of_step": round(ms / (dt * 1e3), 4)}
+                                      "algorithmic_bytes_per_launch": round(nb / len(recs)), "share_of_step": round((ms / psteps) / (dt / args.steps * 1e3), 4)}
                 if fl > 0:     # arithmetic outweighs bytes (the FFT frontend: 87 flop per byte): the fp32 vector rate is the nearer bound
                     tf = fl / (ms * 1e-3) / 1e12
                     hbm_kernels[kname]["nearer_bound"] = {"bound": "valu_f32", "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -258,16 +291,19 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "encoder": model_type, "clip_seconds": seconds, "n_mels": 64,
                        "clips_per_gpu": B, "global_batch": B * world, "step": "logmel+augment+fwd+bwd+allreduce+adamw" +
-                       ("+ema" if mode == "byol" else ""), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
+                       ("+ema" if mode == "byol" else ""), "hip_graph": trainer._graph is not None,
+                       "eager_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
                        "loss": round(loss_val, 4)},
             "roofline": {"bound": "mfma", "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
                          "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_note": traffic_note,
                          "algorithmic_flop_per_launch": round(d_fl / d_n), "algorithmic_bytes_per_launch": round(d_nb / d_n),
                          "launches": d_n, "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
-                         "share_of_step": round(d_ms / (dt * 1e3), 4),
+                         "share_of_step": round((d_ms / psteps) / (dt / args.steps * 1e3), 4),
+                         "timing": f"HIP events on the launch stream around every sa_gemm_bf16 launch of {psteps} eager steps run right after the timed region "
+                                   f"(the timed region replays the step as a HIP graph: {'yes' if trainer._graph is not None else 'no'})",
                          "all_gemm": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": len(prof),
-                                      "share_of_step": round(gemm_ms / (dt * 1e3), 4),
+                                      "share_of_step": round((gemm_ms / psteps) / (dt / args.steps * 1e3), 4),
                                       "by_kernel": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[3],
                                                         "avg_launch_us": round(v[0] * 1e3 / v[3], 2)} for k, v in by_kernel.items() if v[0] > 0},
                                       "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0}},

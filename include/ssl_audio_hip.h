@@ -150,6 +150,13 @@ int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_
 int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream);
 int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream);
+/* The same two updates with everything that changes from step to step read from DEVICE memory, so that a launch captured in a HIP
+ * graph replays correctly: hyper3 = {lr (the value utils.adjust_learning_rate set, utils/utils.py:47-65), 1 / (1 - beta1^t),
+ * 1 / sqrt(1 - beta2^t)}; skip_flag (optional): when *skip_flag != 0 the launch changes nothing -- the counterpart of
+ * main_bt_byol.py:116-118 (a non-finite loss stops training BEFORE optimizer.step()) for a host that reads the flag lazily. */
+int sa_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper3, float beta1, float beta2, float eps,
+                      float weight_decay, float grad_scale, void* p_bf16, const int32_t* skip_flag, void* stream);
+int sa_ema_update_gated(float* target, const float* online, int64_t n, float beta, const int32_t* skip_flag, void* stream);
 /* LARS on one parameter tensor (utils/utils.py:150-189, selected by `--optimizer LARS`, main_bt_byol.py:326-345):
  * dp = g + weight_decay * p (pass 0 where the reference's weight_decay_filter excludes the tensor);
  * lars_adaptation != 0: dp *= eta * |p| / |dp| (1 when either norm is 0); mu = momentum * mu + dp; p -= lr * mu.

@@ -11,7 +11,8 @@ def encoder_frames(x, p, keep=None, drop_p=0.3, bn_stats=None, conv_layers=2):
     (None = no dropout, i.e. eval-mode dropout with train-mode BatchNorm)."""
     h = x
     for l in range(conv_layers):
-        h = R.qb(F.conv2d(R.qf(h), R.qw(p[f"features.{4 * l}.weight"]), p[f"features.{4 * l}.bias"], stride=1, padding=1))
+        qf, qw = (R.qf, R.qw) if l > 0 else ((lambda t: t), (lambda t: t))     # first convolution (C_in = 1): direct fp32 kernel on the HIP path
+        h = R.qb(F.conv2d(qf(h), qw(p[f"features.{4 * l}.weight"]), p[f"features.{4 * l}.bias"], stride=1, padding=1))
         if bn_stats is not None:
             bn_stats.append((h.mean((0, 2, 3)).detach(), h.var((0, 2, 3), unbiased=False).detach(), h.numel() // h.shape[1]))
         h = F.relu(F.batch_norm(h, None, None, p[f"features.{4 * l + 1}.weight"], p[f"features.{4 * l + 1}.bias"], True, 0.1, 1e-5))

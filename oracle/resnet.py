@@ -23,14 +23,22 @@ def _pair(s):
     return tuple(s) if isinstance(s, (tuple, list)) else (s, s)
 
 
+_TRAINING = [True]          # forward(..., training=False): nn.BatchNorm2d in eval mode, i.e. the running statistics of the state dict
+
+
 def _bn(h, p, name, bn_stats):
+    if not _TRAINING[0]:
+        return F.batch_norm(h, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"], p[name + ".bias"], False, 0.1, 1e-5)
     if bn_stats is not None:
         bn_stats.append((name, h.mean((0, 2, 3)).detach(), h.var((0, 2, 3), unbiased=False).detach(), h.numel() // h.shape[1]))
     return F.batch_norm(h, None, None, p[name + ".weight"], p[name + ".bias"], True, 0.1, 1e-5)
 
 
 def _conv(a, p, name, stride, padding):
-    # the HIP path stores the convolution's input activation and weight as bf16, and consumes the output gradient as bf16
+    # the HIP path stores the convolution's input activation and weight as bf16, and consumes the output gradient as bf16 -- except the
+    # single-input-channel first convolution, a direct fp32 kernel (fp32 image, fp32 weight)
+    if a.shape[1] == 1:
+        return R.qb(F.conv2d(a, p[name + ".weight"], None, stride=_pair(stride), padding=padding))
     return R.qb(F.conv2d(R.qf(a), R.qw(p[name + ".weight"]), None, stride=_pair(stride), padding=padding))
 
 
@@ -44,8 +52,16 @@ def basic_block(x, p, pre, stride, bn_stats=None):
     return F.relu(out + identity)
 
 
-def forward(x, p, variant="resnet18", bn_stats=None):
+def forward(x, p, variant="resnet18", bn_stats=None, training=True):
     """ResNet._forward_impl (models/resnet.py:255-274) with fc = Identity.  x [B, 1, F, T] -> [B, embed_dim]."""
+    _TRAINING[0] = training
+    try:
+        return _forward(x, p, variant, bn_stats)
+    finally:
+        _TRAINING[0] = True
+
+
+def _forward(x, p, variant, bn_stats):
     cfg = VARIANTS[variant]
     s = cfg["strides"]
     h = x

@@ -174,15 +174,22 @@ CONVSTEM_STRIDES = {  # models/mae.py:58-67
 def conv_stem(x, p, patch, bn_stats=None):
     """ConvStem.forward (models/mae.py:89-99): [3x3 conv (no bias) -> BatchNorm2d (train mode: batch statistics) -> ReLU] per
     stride entry, then a 1x1 conv with bias; tokens = flatten(2).transpose(1, 2).  `bn_stats` (list) receives (mean, biased var, n)
-    per BatchNorm for the running-statistics replay.  Hooks: operands of every conv are bf16 on the HIP path (R.qf / R.qw), the
+    per BatchNorm for the running-statistics replay; bn_stats = "eval" selects eval mode (running statistics, nothing recorded).  Hooks: operands of every conv are bf16 on the HIP path (R.qf / R.qw), the
     pre-BatchNorm maps are fp32 with bf16 gradients (R.qb)."""
     strides = CONVSTEM_STRIDES[tuple(patch)]
     h = x
     for l, st in enumerate(strides):
-        h = R.qb(F.conv2d(R.qf(h), R.qw(p[f"patch_embed.proj.{3 * l}.weight"]), None, stride=st, padding=1))
+        # (the single-input-channel first convolution is a direct fp32 kernel on the HIP path: fp32 image, fp32 weight; only its
+        # output gradient is consumed as bf16)
+        qf, qw = (R.qf, R.qw) if l > 0 else ((lambda t: t), (lambda t: t))
+        h = R.qb(F.conv2d(qf(h), qw(p[f"patch_embed.proj.{3 * l}.weight"]), None, stride=st, padding=1))
+        bn = f"patch_embed.proj.{3 * l + 1}"
+        if bn_stats == "eval":                               # nn.BatchNorm2d in eval mode: the running statistics of the state dict
+            h = F.relu(F.batch_norm(h, p[bn + ".running_mean"], p[bn + ".running_var"], p[bn + ".weight"], p[bn + ".bias"], False, 0.1, 1e-5))
+            continue
         if bn_stats is not None:
             bn_stats.append((h.mean((0, 2, 3)).detach(), h.var((0, 2, 3), unbiased=False).detach(), h.numel() // h.shape[1]))
-        h = F.relu(F.batch_norm(h, None, None, p[f"patch_embed.proj.{3 * l + 1}.weight"], p[f"patch_embed.proj.{3 * l + 1}.bias"], True, 0.1, 1e-5))
+        h = F.relu(F.batch_norm(h, None, None, p[bn + ".weight"], p[bn + ".bias"], True, 0.1, 1e-5))
     last = 3 * len(strides)
     h = R.qb(F.conv2d(R.qf(h), R.qw(p[f"patch_embed.proj.{last}.weight"]), p[f"patch_embed.proj.{last}.bias"]))
     return h.flatten(2).transpose(1, 2)

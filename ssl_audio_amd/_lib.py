@@ -91,6 +91,8 @@ _SIGNATURES = {
     "sa_bt_loss_grad": [P, I32, F32, F32, I32, P, P, P],
     "sa_adamw_step": [P, P, P, P, I64, F32, F32, F32, F32, F32, I32, F32, P, P],
     "sa_ema_update": [P, P, I64, F32, P],
+    "sa_adamw_step_dev": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, P, P, P],
+    "sa_ema_update_gated": [P, P, I64, F32, P, P],
     "sa_axpy_f32": [P, P, I64, F32, P],
     "sa_count_nonfinite": [P, I64, P, P],
     "sa_logmel_fwd": [P, I64, I32, I32, P, P, P, P, P, P, I64, I32, I32, F32, F32, I32, P],

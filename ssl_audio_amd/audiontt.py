@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import dist as sdist
 from . import ops
-from .convstem import _bn_forward, _kpad, _pack_conv_weight
+from .convstem import _bn_forward, _kpad, _pack_conv_weight, bn_bwd_sums
 from .engine import BF16_WEIGHTS, _wgrad, grad_target
 
 BF16 = torch.bfloat16
@@ -113,6 +113,7 @@ class AudioNTTFn(torch.autograd.Function):
         ctx.saved = (x, h1, m1, r1, p1, i1, h2, m2, r2, i2, X, h3, a3, h4, arg, keep, scale)
         ctx.dims = (B, H, W, C, conv_d, hid, dfc)
         ctx.params = (w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, w4, b4)
+        ctx.train = train
         return out
 
     @staticmethod
@@ -154,7 +155,7 @@ class AudioNTTFn(torch.autograd.Function):
             ops.bn_bwd_stats_tall(da, h, mean, rstd, gamma, beta, True, s[0], s[1])
             dgb, dg = grad_target(gamma); dbb, dbt = grad_target(beta)
             ops.axpy(dbb, s[0]); ops.axpy(dgb, s[1])
-            sdist.all_reduce_sum_(s)
+            s = bn_bwd_sums(s, ctx.train)
             dh = torch.empty(rows, C, dtype=BF16, device=dev)
             ops.bn_bwd_apply(da, h, mean, rstd, gamma, beta, True, s[0], s[1], 1.0 / (rows * Wn), dx_bf16=dh)
             return dh, dg, dbt

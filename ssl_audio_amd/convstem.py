@@ -73,10 +73,13 @@ class ConvStem(nn.Module):
         return convs, bns, self.proj[3 * n]
 
 
-def _bn_forward(h, B_rows, bn):
-    """Batch statistics of a tall [M, C] map (SyncBN over ranks) -> mean, rstd; running buffers updated like nn.BatchNorm2d."""
+def _bn_forward(h, B_rows, bn, training=True):
+    """Training: batch statistics of a tall [M, C] map (SyncBN over ranks) -> mean, rstd; running buffers updated like nn.BatchNorm2d.
+    Eval (`bn.eval()`, nn.BatchNorm2d's inference form): the running statistics -- no column pass, no collective, buffers untouched."""
     M, Cn = h.shape
     dev = h.device
+    if not training:
+        return bn.running_mean.detach(), torch.rsqrt(bn.running_var.detach() + bn.eps)
     stats = torch.empty(2, Cn, device=dev)
     ops.bn_colstats_tall(h, stats[0], stats[1])
     allst = sdist.all_gather_rows(stats)
@@ -85,6 +88,15 @@ def _bn_forward(h, B_rows, bn):
     with torch.no_grad():
         bn.num_batches_tracked += 1
     return mean, rstd
+
+
+def bn_bwd_sums(s, training):
+    """The two sums the BatchNorm input gradient subtracts: the cross-rank totals in training; zeros in eval, where the layer is the
+    fixed affine map of its running statistics and dx = gamma * rstd * dy (the parameter gradients are the local sums either way)."""
+    if training:
+        sdist.all_reduce_sum_(s)
+        return s
+    return torch.zeros_like(s)
 
 
 def _pack_conv_weight(w, kpad, rows=None):
@@ -129,7 +141,7 @@ class ConvStemTokensFn(torch.autograd.Function):
                 ops.im2col3x3(a, S, H, W, Ci, (sh, sw), P)
                 ops.gemm(P, _pack_conv_weight(convs[l].weight, kp), out_f32=h)
                 del P
-            mean, rstd = _bn_forward(h, M, bns[l])
+            mean, rstd = _bn_forward(h, M, bns[l], stem.training)
             a_next = torch.empty(M, Co, dtype=BF16, device=dev)
             ops.bn_apply(h, mean, rstd, bns[l].weight.detach(), bns[l].bias.detach(), True, y_bf16=a_next)
             saved.append((a, h, mean, rstd))
@@ -156,6 +168,7 @@ class ConvStemTokensFn(torch.autograd.Function):
         ctx.stem, ctx.saved, ctx.dims, ctx.x, ctx.a_last = stem, saved, dims, x, a
         ctx.cls_param = cls_token
         ctx.L = L
+        ctx.train = stem.training
         return tok
 
     @staticmethod
@@ -201,7 +214,7 @@ class ConvStemTokensFn(torch.autograd.Function):
             dbb2, grads_b[l] = grad_target(beta)
             ops.axpy(dbb2, s[0])
             ops.axpy(dgb, s[1])
-            sdist.all_reduce_sum_(s)
+            s = bn_bwd_sums(s, ctx.train)
             cpad = Co if l == 0 else (Co + 63) // 64 * 64            # zero columns up to the dgrad GEMM's K granule
             dh_full = torch.zeros(M, cpad, dtype=BF16, device=dev) if cpad != Co else torch.empty(M, Co, dtype=BF16, device=dev)
             dh = dh_full[:, :Co]

@@ -209,9 +209,14 @@ __global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restri
 }
 
 // ---- flat elementwise: AdamW (torch.optim.AdamW semantics, decoupled decay), EMA, scaled add
+// hyper (optional, device): {lr, 1 / (1 - b1^t), 1 / sqrt(1 - b2^t)} replace the scalar arguments -- what changes from step to step then
+// lives in memory, so a captured launch (HIP graph) replays with the current values; skip (optional, device): a non-zero word (the
+// trainer's non-finite-loss counter) turns the launch into a no-op, so a NaN loss never reaches the weights or the moments.
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                              float lr, float b1, float b2, float eps, float wd, float inv_c1, float inv_sqrt_c2, float grad_scale,
-                             bf16_t* __restrict__ p_bf16) {
+                             bf16_t* __restrict__ p_bf16, const float* __restrict__ hyper, const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
+  if (hyper) { lr = hyper[0]; inv_c1 = hyper[1]; inv_sqrt_c2 = hyper[2]; }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
     float pi = p[i] * (1.f - lr * wd);
@@ -227,7 +232,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // 16-byte version for buffers whose pointers are 16-byte aligned and whose length is a multiple of 4 (the flat state is)
 __global__ __launch_bounds__(256) void adamw_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                                                          float4* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float wd,
-                                                         float inv_c1, float inv_sqrt_c2, float grad_scale, bf16x4* __restrict__ p_bf16) {
+                                                         float inv_c1, float inv_sqrt_c2, float grad_scale, bf16x4* __restrict__ p_bf16,
+                                                         const float* __restrict__ hyper, const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
+  if (hyper) { lr = hyper[0]; inv_c1 = hyper[1]; inv_sqrt_c2 = hyper[2]; }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 gi = g[i], pi = p[i], mi = m[i], vi = v[i];
     float gg[4] = {gi.x * grad_scale, gi.y * grad_scale, gi.z * grad_scale, gi.w * grad_scale};
@@ -248,7 +256,8 @@ __global__ __launch_bounds__(256) void adamw_vec4_kernel(float4* __restrict__ p,
   }
 }
 
-__global__ void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n, float beta) {
+__global__ void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, int64_t n, float beta, const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     tgt[i] = tgt[i] * beta + (1.f - beta) * src[i];
 }
@@ -380,28 +389,50 @@ extern "C" int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lam
   return 0;
 }
 
+namespace {
+int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float inv_c1, float inv_sqrt_c2, float grad_scale, void* p_bf16, const float* hyper, const int32_t* skip, void* stream) {
+  const bool vec = (n % 4 == 0) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)p_bf16 & 7) == 0);
+  if (vec)
+    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(flat_grid(n / 4, 2)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, n / 4, lr, beta1, beta2, eps, weight_decay, inv_c1, inv_sqrt_c2, grad_scale, (bf16x4*)p_bf16, hyper, skip);
+  else
+    hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, inv_c1, inv_sqrt_c2, grad_scale, (bf16_t*)p_bf16, hyper, skip);
+  SA_LAUNCH_CHECK("sa_adamw_step");
+  return 0;
+}
+}  // namespace
+
 extern "C" int sa_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, float grad_scale, void* p_bf16, void* stream) {
   SA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "sa_adamw_step: bad args");
   if (n == 0) return 0;
   const double c1 = 1.0 - pow((double)beta1, (double)step), c2 = 1.0 - pow((double)beta2, (double)step);
-  const bool vec = (n % 4 == 0) && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)p_bf16 & 7) == 0);
-  if (vec)
-    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(flat_grid(n / 4, 2)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g, (float4*)m,
-                       (float4*)v, n / 4, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale,
-                       (bf16x4*)p_bf16);
-  else
-    hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale, (bf16_t*)p_bf16);
-  SA_LAUNCH_CHECK("sa_adamw_step");
-  return 0;
+  return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / c1), (float)(1.0 / sqrt(c2)), grad_scale, p_bf16, nullptr,
+                      nullptr, stream);
+}
+
+extern "C" int sa_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper3, float beta1, float beta2, float eps,
+                                 float weight_decay, float grad_scale, void* p_bf16, const int32_t* skip_flag, void* stream) {
+  SA_CHECK_ARG(p && g && m && v && n >= 0 && hyper3, "sa_adamw_step_dev: bad args (hyper3 = device {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)})");
+  if (n == 0) return 0;
+  return adamw_launch(p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale, p_bf16, hyper3, skip_flag, stream);
 }
 
 extern "C" int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream) {
   SA_CHECK_ARG(target && online && n >= 0, "sa_ema_update: bad args");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta);
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta, (const int32_t*)nullptr);
   SA_LAUNCH_CHECK("sa_ema_update");
+  return 0;
+}
+
+extern "C" int sa_ema_update_gated(float* target, const float* online, int64_t n, float beta, const int32_t* skip_flag, void* stream) {
+  SA_CHECK_ARG(target && online && n >= 0, "sa_ema_update_gated: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, target, online, n, beta, skip_flag);
+  SA_LAUNCH_CHECK("sa_ema_update_gated");
   return 0;
 }
 

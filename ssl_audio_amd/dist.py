@@ -96,24 +96,65 @@ class GradSumParallel(nn.Module):
     the wrapped parameters are SUMMED over ranks -- summed, not averaged: losses here are global-batch exact (every rank holds
     the loss of the global batch and back-propagates its own rows' share of it).
 
-    Mechanics: a post-accumulate hook per parameter collects ready gradients into buckets of `bucket_bytes`; a full bucket is
-    flattened and all-reduced asynchronously on a side stream (RCCL) while the backward goes on; a callback queued on the
-    autograd engine for the end of the pass flushes the last bucket, joins the stream and scatters the sums back into `.grad`.
-    One backward per optimiser step, like DDP without no_sync().
+    Mechanics: the trainable parameters are assigned ONCE, in reverse registration order (the order a backward pass finishes them
+    in), to buckets of `bucket_bytes`; each bucket owns a flat fp32 buffer and every parameter's `.grad` is (re)pointed at its slice
+    of it, so a bucket is all-reduced IN PLACE -- no flatten copy before the collective and no scatter copy after it (a gradient that
+    autograd allocated afresh, e.g. after `zero_grad(set_to_none=True)`, costs one copy into its slice).  A post-accumulate hook per
+    parameter counts arrivals; a complete bucket is reduced asynchronously on a side stream (RCCL) while the backward goes on; a
+    callback queued on the autograd engine for the end of the pass reduces what is left (buckets that stayed incomplete because some
+    parameter received no gradient) and joins the stream.  Static buckets make the collective sequence identical on every rank
+    whatever order the hooks fire in.  One backward per optimiser step, like DDP without no_sync(): a second backward before the
+    step would sum the first one's (already reduced) gradients again and raises instead.
     """
 
     def __init__(self, module, bucket_bytes=64 << 20):
         super().__init__()
         self.module = module
         self.bucket_bytes = bucket_bytes
-        self._pending, self._pending_bytes, self._inflight, self._armed = [], 0, [], False
         self._stream = None
-        for p in module.parameters():
-            if p.requires_grad:
+        self._buckets = []                          # [params], in reduction order
+        self._where = {}                            # id(p) -> (bucket index, element offset)
+        cur, cur_bytes = [], 0
+        for p in reversed([q for q in module.parameters() if q.requires_grad]):
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= bucket_bytes:
+                self._buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._buckets.append(cur)
+        for b, params in enumerate(self._buckets):
+            off = 0
+            for p in params:
+                self._where[id(p)] = (b, off)
+                off += (p.numel() + 3) // 4 * 4     # 16-byte aligned slices
                 p.register_post_accumulate_grad_hook(self._on_grad)
+        self._flat = [None] * len(self._buckets)    # allocated on the first backward (the parameters' device is final by then)
+        self._reset()
+
+    def _reset(self):
+        self._arrived = [0] * len(self._buckets)
+        self._seen = set()
+        self._launched = [False] * len(self._buckets)
+        self._inflight = []
+        self._armed = False
 
     def forward(self, *args, **kwargs):
+        if self._armed or self._inflight:           # a backward that raised never reached _finish: drop its half-built state
+            for work in self._inflight:
+                try:
+                    work.wait()
+                except Exception:
+                    pass
+            self._reset()
         return self.module(*args, **kwargs)
+
+    def _bucket_buffer(self, b):
+        if self._flat[b] is None:
+            params = self._buckets[b]
+            n = sum((p.numel() + 3) // 4 * 4 for p in params)
+            self._flat[b] = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        return self._flat[b]
 
     def _on_grad(self, p):
         if not collectives_active() or p.grad is None:
@@ -121,16 +162,29 @@ class GradSumParallel(nn.Module):
         if not self._armed:
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
             self._armed = True
-        self._pending.append(p)
-        self._pending_bytes += p.grad.numel() * p.grad.element_size()
-        if self._pending_bytes >= self.bucket_bytes:
-            self._launch()
+        if id(p) in self._seen:
+            raise RuntimeError("GradSumParallel: a parameter received a second gradient before the end of the backward pass was "
+                               "reached -- one backward per optimiser step (the first pass's gradients are already summed over ranks)")
+        self._seen.add(id(p))
+        b, off = self._where[id(p)]
+        flat = self._bucket_buffer(b)
+        view = flat[off:off + p.numel()].view_as(p)
+        if p.grad.data_ptr() != view.data_ptr():    # autograd allocated this gradient: move it into the bucket, keep the view
+            view.copy_(p.grad)
+            p.grad = view
+        self._arrived[b] += 1
+        if self._arrived[b] == len(self._buckets[b]):
+            self._launch(b)
 
-    def _launch(self):
-        params, self._pending, self._pending_bytes = self._pending, [], 0
-        if not params:
+    def _launch(self, b):
+        if self._launched[b]:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        self._launched[b] = True
+        flat = self._bucket_buffer(b)
+        for q in self._buckets[b]:                  # a parameter without a gradient this pass contributes zeros (its slice may be stale)
+            if id(q) not in self._seen:
+                _, off = self._where[id(q)]
+                flat[off:off + q.numel()].zero_()
         if flat.is_cuda and dist.get_backend() == "nccl":
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
@@ -139,19 +193,15 @@ class GradSumParallel(nn.Module):
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self._inflight.append((flat, params, work))
+        self._inflight.append(work)
 
     def _finish(self):
-        self._launch()
-        for flat, params, work in self._inflight:
-            work.wait()
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        for flat, params, _ in self._inflight:
-            off = 0
-            for p in params:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
-        self._inflight.clear()
-        self._armed = False
+        try:
+            for b in range(len(self._buckets)):     # every rank reduces every bucket, in bucket order
+                self._launch(b)
+            for work in self._inflight:
+                work.wait()
+            if self._stream is not None:
+                torch.cuda.current_stream().wait_stream(self._stream)
+        finally:
+            self._reset()

@@ -5,10 +5,11 @@ C-ABI launches per transformer block with fused epilogues and a hand-planned set
 
   fwd block:  LN1 -> [qkv GEMM + (q,0,v) bias] -> fused attention -> [proj GEMM + bias + residual]
               -> LN2 -> [fc1 GEMM + bias + GELU (pre-activation kept)] -> [fc2 GEMM + bias + residual]
-  bwd block:  mirrors it; every dgrad is an NN GEMM on the untransposed bf16 weight, every wgrad a TN split-K
-              GEMM accumulating fp32 atomics into the gradient buffer, GELU' fused into the fc2 dgrad epilogue,
-              LayerNorm backward fused with the residual-gradient add and emitting the bf16 copy the next
-              GEMMs consume.
+  bwd block:  mirrors it; every dgrad runs in the forward operand layout (NT) against a transposed bf16 copy of the
+              weight (rebuilt once per optimiser step), every wgrad is a TN split-K GEMM whose slices are summed in slice
+              order by a second launch (bit-reproducible; SA_DETERMINISTIC=0: fp32 atomics), GELU' -- stored by the fc1
+              forward -- multiplied in by the fc2 dgrad epilogue, LayerNorm backward fused with the residual-gradient
+              add and emitting the bf16 copy the next GEMMs consume.
 
 Residual stream fp32, GEMM operands / attention bf16, accumulation fp32.  `torch` only provides device
 memory here.  The autograd.Function at the bottom exposes the schedule to nn.Module callers.
@@ -43,6 +44,7 @@ class _Bf16Cache:
         touch torch's version counter.  Anything that DOES bump it (load_state_dict, an in-place torch op on the parameter)
         changed the master behind the optimiser's back: the copy is re-cast on the next use."""
         self._pinned[id(p)] = [w16, p.data_ptr(), weakref.ref(p), p._version]
+        _forget_when_dead(p, self._pinned, self._manual)
 
     def get(self, p):
         # id() values are recycled once a parameter dies, so every entry carries a weak reference to ITS parameter
@@ -59,8 +61,21 @@ class _Bf16Cache:
             w = p.detach()
             w2 = w.reshape(w.shape[0], -1) if w.dim() > 1 else w
             ent = (ver, ops.cast_bf16(w2.contiguous()), p.data_ptr(), weakref.ref(p))
+            if key not in self._c:
+                _forget_when_dead(p, self._c, self._manual)
             self._c[key] = ent
         return ent[1]
+
+
+def _forget_when_dead(p, *tables):
+    """Entries of the id()-keyed tables die with their parameter: each one pins device memory (a bf16 copy of a weight, a view that
+    keeps a whole flat buffer alive), and models are rebuilt many times in one process by tests and sweeps."""
+    key = id(p)
+
+    def drop():
+        for t in tables:
+            t.pop(key, None)
+    weakref.finalize(p, drop)
 
 
 BF16_WEIGHTS = _Bf16Cache()
@@ -85,6 +100,8 @@ class _Bf16TransposedCache:
         ent = self._c.get(key)
         if ent is None or ent[2]() is not p or ent[0] != ver:
             buf = ent[1] if ent is not None and ent[2]() is p and ent[1].shape == (w16.shape[1], w16.shape[0]) and ent[1].device == w16.device else None
+            if key not in self._c:
+                _forget_when_dead(p, self._c)
             ent = (ver, ops.transpose_bf16(w16.contiguous(), buf), weakref.ref(p))
             self._c[key] = ent
         return ent[1]
@@ -101,16 +118,32 @@ def _dgrad_w(w):
         return BF16_WEIGHTS_T.get(w), True
     return BF16_WEIGHTS.get(w), False
 
-# id(parameter) -> fp32 buffer (normally a view into train.FlatState's flat gradient buffer).  When a parameter has a
-# sink, the backward kernels accumulate straight into it and autograd is handed None (no per-parameter allocation,
-# no autograd accumulate pass, and the flat buffer is what the gradient all-reduce and the fused AdamW consume).
+# id(parameter) -> (weakref(parameter), fp32 buffer, weakref(owner)): the buffer is normally a view into the flat gradient buffer of
+# the owning train.FlatState.  When a parameter has a sink, the backward kernels accumulate straight into it and autograd is handed
+# None (no per-parameter allocation, no autograd accumulate pass, and the flat buffer is what the gradient all-reduce and the fused
+# AdamW consume).
 GRAD_SINK = {}
-# called as BLOCK_DONE_HOOK(params_of_block) once a transformer block's gradients are FINAL (train.GradSync overlaps the
-# gradient all-reduce of that block with the remaining backward).  A block can be visited by several encoder passes of one
-# step (mode 'mae': masked view 1 and unmasked view 2; MultiCropWrapper with two crop widths): every forward pass that will
-# be differentiated arms one pending backward per block, and the hook fires when the LAST of them has run.
-BLOCK_DONE_HOOK = None
 _PENDING_BWD = {}
+
+
+def register_grad_sink(p, view, owner):
+    GRAD_SINK[id(p)] = (weakref.ref(p), view, weakref.ref(owner))
+    _forget_when_dead(p, GRAD_SINK)
+
+
+def block_done_hook(p):
+    """The callable to run once the gradients of the transformer block that owns parameter `p` are FINAL, or None: the
+    `block_done` of the gradient synchroniser (train.GradSync) attached to the FlatState that holds p's gradient sink -- instance
+    state of that trainer, so several live trainers (online / probe / a second model) never see each other's blocks.  A block can be
+    visited by several encoder passes of one step (mode 'mae': masked view 1 and unmasked view 2; MultiCropWrapper with two crop
+    widths): every forward pass that will be differentiated arms one pending backward per block, and the hook fires when the LAST of
+    them has run."""
+    ent = GRAD_SINK.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    owner = ent[2]()
+    sync = getattr(owner, "sync", None) if owner is not None else None
+    return sync.block_done if (sync is not None and sync.active) else None
 
 
 def reset_pending_backward():
@@ -359,7 +392,7 @@ class EncoderFn(torch.autograd.Function):
                 ops.mean_tokens_fwd(y.view(S, N, d), out)
             else:
                 out = y.view(S, N, d)
-        if need_grad and BLOCK_DONE_HOOK is not None:
+        if need_grad and n_blocks and block_done_hook(params[2]) is not None:
             for i in range(n_blocks):
                 key = id(params[13 * i + 2])
                 _PENDING_BWD[key] = _PENDING_BWD.get(key, 0) + 1
@@ -415,13 +448,14 @@ class EncoderFn(torch.autograd.Function):
             else:
                 dx, dx16 = block_backward(dx, dx16, bp, bg, H, N, ctx.saved[i], b2_done=(i < n_blocks - 1), prev_b2=prev_b2)
             ctx.saved[i] = None
-            if BLOCK_DONE_HOOK is not None:
+            hook = block_done_hook(params[13 * i + 2])
+            if hook is not None:
                 key = id(params[13 * i + 2])
                 left = _PENDING_BWD.get(key, 1) - 1
                 _PENDING_BWD[key] = left
                 if left <= 0:
                     _PENDING_BWD.pop(key, None)
-                    BLOCK_DONE_HOOK(params[13 * i:13 * (i + 1)])
+                    hook(params[13 * i:13 * (i + 1)])
         dtok = dx.view(S, N, d) if ctx.needs_input_grad[0] else None
         return (dtok, None, None, None, None, *grads)
 

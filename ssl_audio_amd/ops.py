@@ -87,8 +87,14 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
     if out_bf16 is not None:
         a.out_bf16, a.ldo_bf16 = _req(out_bf16, BF16, "out_bf16").data_ptr(), _rows(out_bf16, "out_bf16")[2]
     a.row_group, a.split_k, a.accumulate, a.tile256 = row_group, split_k, int(accumulate), int(tile256)
-    if split_k > 1 and DETERMINISTIC_WGRAD and N % 4 == 0:
-        a.splitk_ws = _workspace(lib().sa_gemm_splitk_workspace_bytes(M, N, split_k), A.device, "gemm_splitk").data_ptr()
+    if split_k > 1 and DETERMINISTIC_WGRAD:
+        if N % 4 == 0:
+            a.splitk_ws = _workspace(lib().sa_gemm_splitk_workspace_bytes(M, N, split_k), A.device, "gemm_splitk").data_ptr()
+        elif N not in _NONDET_WARNED:                # the slice-ordered reduce works on float4 columns
+            _NONDET_WARNED.add(N)
+            import warnings
+            warnings.warn(f"sa_gemm_bf16: split-K output with N = {N} (not a multiple of 4) falls back to fp32 atomics: this weight "
+                          "gradient is summed in a run-dependent order (reproducible to fp32 rounding, not bit for bit)")
     if colsum_out is not None:          # colsum_out[n] += sum_m (fp32 epilogue result)[m][n], through a scratch of per-64-row partials
         ws = _workspace(lib().sa_gemm_colsum_workspace_bytes(M, N), A.device, "gemm_colsum")
         a.colsum_out, a.colsum_ws = _req(colsum_out, F32, "colsum_out").data_ptr(), ws.data_ptr()
@@ -112,6 +118,7 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
 
 
 _WORKSPACES = {}
+_NONDET_WARNED = set()
 
 
 def _workspace(nbytes, device, tag):
@@ -305,6 +312,18 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf
     _timed("adamw_vec4_kernel", float(n) * (28 + (2 if p_bf16 is not None else 0)), lambda: check(
         lib().sa_adamw_step(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
                             float(grad_scale), _p(p_bf16), _stream()), "sa_adamw_step"))
+
+
+def adamw_step_dev(p, g, m, v, hyper3, beta1, beta2, eps, wd, grad_scale=1.0, p_bf16=None, skip_flag=None):
+    """adamw_step with {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)} read from the device vector hyper3 (graph-replayable) and an optional gate word."""
+    n = p.numel()
+    _timed("adamw_vec4_kernel", float(n) * (28 + (2 if p_bf16 is not None else 0)), lambda: check(
+        lib().sa_adamw_step_dev(_p(p), _p(g), _p(m), _p(v), n, _p(_req(hyper3, F32, "hyper3")), float(beta1), float(beta2), float(eps), float(wd),
+                                float(grad_scale), _p(p_bf16), _p(skip_flag), _stream()), "sa_adamw_step_dev"))
+
+
+def ema_update_gated(target, online, beta, skip_flag):
+    check(lib().sa_ema_update_gated(_p(target), _p(online), target.numel(), float(beta), _p(skip_flag), _stream()), "sa_ema_update_gated")
 
 
 def lars_step(p, g, mu, lr, wd, momentum, eta, adapt, scratch2=None, p_bf16=None):

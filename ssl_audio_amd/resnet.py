@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import dist as sdist
 from . import ops
-from .convstem import BN_EPS, BN_MOMENTUM, _bn_forward, _kpad, _pack_conv_weight
+from .convstem import BN_EPS, BN_MOMENTUM, _bn_forward, _kpad, _pack_conv_weight, bn_bwd_sums
 from .engine import BF16_WEIGHTS, _wgrad, grad_target
 
 BF16 = torch.bfloat16
@@ -108,10 +108,10 @@ def resnet18_ReGP_NRF():
 # ---------------------------------------------------------------------------------------------------------------------------------
 class _ConvBN:
     """One convolution + BatchNorm2d of the forward, with what its backward needs."""
-    __slots__ = ("conv", "bn", "k", "stride", "relu", "S", "H", "W", "Ci", "Ho", "Wo", "Co", "a_in", "x_img", "h", "mean", "rstd")
+    __slots__ = ("conv", "bn", "k", "stride", "relu", "S", "H", "W", "Ci", "Ho", "Wo", "Co", "a_in", "x_img", "h", "mean", "rstd", "train")
 
 
-def _conv_bn_fwd(conv, bn, a16, S, H, W, Ci, relu, x_img=None):
+def _conv_bn_fwd(conv, bn, a16, S, H, W, Ci, relu, x_img=None, training=True):
     """a16 bf16 [S*H*W, Ci] (or x_img fp32 [S,1,H,W] for the single-channel first layer) -> record with h = conv output (fp32) and the
     batch statistics.  3x3 (pad 1) through im2col + GEMM, 1x1 through row subsampling + GEMM."""
     r = _ConvBN()
@@ -144,7 +144,8 @@ def _conv_bn_fwd(conv, bn, a16, S, H, W, Ci, relu, x_img=None):
             ops.subsample_fwd(a16, S, H, W, Ci, r.stride, xs)
         r.a_in = xs                                              # the 1x1 convolution's GEMM operand (already subsampled)
         ops.gemm(xs, BF16_WEIGHTS.get(conv.weight), out_f32=r.h)
-    r.mean, r.rstd = _bn_forward(r.h, M, bn)
+    r.train = training
+    r.mean, r.rstd = _bn_forward(r.h, M, bn, training)
     return r
 
 
@@ -163,7 +164,7 @@ def _conv_bn_bwd(r, dz, grads, dx_out=None, need_dx=True):
     dbb, grads[id(beta)] = grad_target(beta)
     ops.axpy(dbb, s[0])
     ops.axpy(dgb, s[1])
-    sdist.all_reduce_sum_(s)
+    s = bn_bwd_sums(s, r.train)
     cpad = (Co + 63) // 64 * 64 if r.x_img is None else Co            # zero columns up to the dgrad GEMM's K granule
     dh_full = torch.zeros(M, cpad, dtype=BF16, device=dev) if cpad != Co else torch.empty(M, Co, dtype=BF16, device=dev)
     dh = dh_full[:, :Co]
@@ -220,11 +221,12 @@ class ResNetFn(torch.autograd.Function):
         x = x.contiguous()
         tape = []
         # ---- ResNet-C stem (models/resnet.py:177-188)
-        r = _conv_bn_fwd(net.conv1[0], net.conv1[1], None, S, F_, T_, 1, True, x_img=x)
+        tr = net.training
+        r = _conv_bn_fwd(net.conv1[0], net.conv1[1], None, S, F_, T_, 1, True, x_img=x, training=tr)
         a = _bn_relu_out(r)
         stem = [r]
         for l in (1, 2):
-            r = _conv_bn_fwd(net.conv1[3 * l], net.conv1[3 * l + 1], a, S, stem[-1].Ho, stem[-1].Wo, stem[-1].Co, True)
+            r = _conv_bn_fwd(net.conv1[3 * l], net.conv1[3 * l + 1], a, S, stem[-1].Ho, stem[-1].Wo, stem[-1].Co, True, training=tr)
             a = _bn_relu_out(r)
             stem.append(r)
         H, W, C = stem[-1].Ho, stem[-1].Wo, stem[-1].Co
@@ -239,15 +241,15 @@ class ResNetFn(torch.autograd.Function):
         # ---- BasicBlocks (models/resnet.py:62-80)
         y16, y32, H, W = p16, p32, Hp, Wp
         for blk in net.blocks():
-            r1 = _conv_bn_fwd(blk.conv1, blk.bn1, y16, S, H, W, C, True)
+            r1 = _conv_bn_fwd(blk.conv1, blk.bn1, y16, S, H, W, C, True, training=tr)
             a1 = _bn_relu_out(r1)
-            r2 = _conv_bn_fwd(blk.conv2, blk.bn2, a1, S, r1.Ho, r1.Wo, r1.Co, False)
+            r2 = _conv_bn_fwd(blk.conv2, blk.bn2, a1, S, r1.Ho, r1.Wo, r1.Co, False, training=tr)
             z = torch.empty(r2.h.shape[0], r2.Co, device=dev)
             ops.bn_apply(r2.h, r2.mean, r2.rstd, blk.bn2.weight.detach(), blk.bn2.bias.detach(), False, y_f32=z)
             rd = None
             idn = y32
             if blk.downsample is not None:
-                rd = _conv_bn_fwd(blk.downsample[0], blk.downsample[1], y16, S, H, W, C, False)
+                rd = _conv_bn_fwd(blk.downsample[0], blk.downsample[1], y16, S, H, W, C, False, training=tr)
                 idn = torch.empty(rd.h.shape[0], rd.Co, device=dev)
                 ops.bn_apply(rd.h, rd.mean, rd.rstd, blk.downsample[1].weight.detach(), blk.downsample[1].bias.detach(), False, y_f32=idn)
             out32 = torch.empty_like(z)

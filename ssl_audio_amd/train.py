@@ -78,13 +78,20 @@ class FlatState:
                 p.data = self.params[off:off + n].view(p.shape)
                 self.offsets[name] = (off, n)
                 if off < self.n_train:
-                    engine.GRAD_SINK[id(p)] = (weakref.ref(p), self.grads[off:off + n].view(p.shape))
+                    engine.register_grad_sink(p, self.grads[off:off + n].view(p.shape), self)
                 if name in self.qkv_fused:
                     engine.QKV_BIAS[id(p)] = (weakref.ref(p), self.params[off:off + 3 * n])
+                    engine._forget_when_dead(p, engine.QKV_BIAS)
             off += pad8(n)
         ops.cast_bf16(self.params, self.params_bf16)
         self.bind_bf16()
         self.step_count = 0
+        # {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)} per parameter group, read by the AdamW launches from DEVICE memory: what changes from step to
+        # step is data, not a kernel argument, so a captured step (HIP graph) replays with the current values.  Staged through pinned host
+        # memory by one small async copy per step.
+        self.hyper = torch.zeros(2, 4, device=device)
+        self._hyper_host = torch.zeros(2, 4).pin_memory() if torch.device(device).type == "cuda" else torch.zeros(2, 4)
+        self.sync = None           # the GradSync that reduces self.grads over ranks (engine.block_done_hook finds it through the sinks)
 
     def bind_bf16(self):
         """Point the engine's bf16 weight cache at views of the flat bf16 buffer (kept fresh by the AdamW kernel)."""
@@ -97,14 +104,39 @@ class FlatState:
     def zero_grad(self):
         self.grads.zero_()
 
-    def adamw(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    def stage_hyper(self, lr, betas=(0.9, 0.999), lr_nodecay=None):
+        """Host side of one optimiser step, OUTSIDE any captured region: advance the step count and send this step's learning rates and
+        bias corrections to the device vector the AdamW launches read."""
+        self.step_count += 1
+        t = self.step_count
+        c1, c2 = 1.0 - betas[0] ** t, 1.0 - betas[1] ** t
+        h = self._hyper_host
+        h[0, 0], h[0, 1], h[0, 2] = lr, 1.0 / c1, 1.0 / math.sqrt(c2)
+        h[1, 0], h[1, 1], h[1, 2] = (lr if lr_nodecay is None else lr_nodecay), 1.0 / c1, 1.0 / math.sqrt(c2)
+        self.hyper.copy_(h, non_blocking=True)
+
+    def adamw_staged(self, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, skip_flag=None):
+        """The two AdamW launches (decayed / un-decayed range) with their per-step scalars read from self.hyper (stage_hyper): capturable.
+        skip_flag: device word; non-zero = leave everything untouched (non-finite loss, main_bt_byol.py:116-118)."""
+        nd, nt = self.n_decay, self.n_train
+        if nd:
+            ops.adamw_step_dev(self.params[:nd], self.grads[:nd], self.m[:nd], self.v[:nd], self.hyper[0], betas[0], betas[1], eps, wd, grad_scale,
+                               self.params_bf16[:nd], skip_flag)
+        if nt > nd:
+            ops.adamw_step_dev(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], self.hyper[1], betas[0], betas[1], eps, 0.0,
+                               grad_scale, self.params_bf16[nd:nt], skip_flag)
+        engine.WEIGHT_EPOCH[0] += 1
+
+    def adamw(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, lr_nodecay=None):
+        """One AdamW step: a launch for the decayed range (lr, wd) and one for the un-decayed range (lr_nodecay or lr, no decay) -- the
+        two parameter groups of utils.get_param_groups, each with the learning rate its group holds."""
         self.step_count += 1
         nd, nt = self.n_decay, self.n_train
         if nd:
             ops.adamw_step(self.params[:nd], self.grads[:nd], self.m[:nd], self.v[:nd], lr, betas[0], betas[1], eps, wd, self.step_count,
                            grad_scale, self.params_bf16[:nd])
         if nt > nd:
-            ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr, betas[0], betas[1], eps, 0.0,
+            ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr if lr_nodecay is None else lr_nodecay, betas[0], betas[1], eps, 0.0,
                            self.step_count, grad_scale, self.params_bf16[nd:nt])
         engine.WEIGHT_EPOCH[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
 
@@ -112,10 +144,11 @@ class FlatState:
     def _trainable(self):
         return [(n, p) for n, p in self.order if p.requires_grad]      # decayed first, then un-decayed: utils.get_param_groups' order
 
-    def optim_state_dict(self, lr, wd, betas=(0.9, 0.999), eps=1e-8):
-        """The Adam moments in `torch.optim.AdamW.state_dict()` form over `utils.get_param_groups(model)`'s parameter order, so that the
-        'optimizer' entry of a checkpoint is interchangeable between this flat state and the reference driver's own optimiser."""
-        state, idx = {}, 0
+    def optim_state_dict(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, index_base=0):
+        """The Adam moments in `torch.optim.AdamW.state_dict()` form over `utils.get_param_groups(module)`'s parameter order: two groups
+        (decayed, un-decayed), parameter indices counted from `index_base`.  main.py's optimiser is exactly this dictionary; main_bt_byol.py's
+        get_optimizer (:301-305) concatenates the encoder's and the predictor's groups -- `merge_optim_state_dicts` builds that form."""
+        state, idx = {}, index_base
         groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=wd, amsgrad=False, maximize=False, foreach=None, capturable=False,
                        differentiable=False, fused=None, params=[]) for _ in range(2)]
         groups[1]["weight_decay"] = 0.0
@@ -127,22 +160,27 @@ class FlatState:
             idx += 1
         return {"state": state, "param_groups": groups}
 
-    def load_optim_state_dict(self, sd):
-        """Inverse of optim_state_dict; accepts what torch.optim.AdamW(utils.get_param_groups(model)).state_dict() wrote."""
+    def load_optim_state_dict(self, sd, first_group=0):
+        """Inverse of optim_state_dict: reads the two parameter groups `first_group`, `first_group + 1` of a torch.optim.AdamW state dict
+        (indices are consecutive over the groups in order, as torch numbers them)."""
         named = self._trainable()
-        n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+        groups = sd["param_groups"]
+        if len(groups) < first_group + 2:
+            raise ValueError(f"optimizer state has {len(groups)} parameter groups, need groups {first_group} and {first_group + 1}")
+        base = sum(len(g["params"]) for g in groups[:first_group])
+        n_saved = len(groups[first_group]["params"]) + len(groups[first_group + 1]["params"])
         if n_saved != len(named):
-            raise ValueError(f"optimizer state has {n_saved} parameters, the model has {len(named)} trainable ones")
+            raise ValueError(f"optimizer state groups {first_group}-{first_group + 1} hold {n_saved} parameters, the module has {len(named)} trainable ones")
         steps = set()
         self.m.zero_()
         self.v.zero_()
         for i, (n, p) in enumerate(named):
-            st = sd["state"].get(i)
+            st = sd["state"].get(base + i)
             if st is None:                                   # a parameter that never received a gradient has no state entry
                 continue
             off, cnt = self.offsets[n]
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
-                raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {n} has {tuple(p.shape)}")
+                raise ValueError(f"optimizer state {base + i} has shape {tuple(st['exp_avg'].shape)}, parameter {n} has {tuple(p.shape)}")
             self.m[off:off + cnt].copy_(st["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
             self.v[off:off + cnt].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
             steps.add(int(float(st["step"])))
@@ -155,12 +193,34 @@ class FlatState:
         ops.cast_bf16(self.params, self.params_bf16)
         engine.WEIGHT_EPOCH[0] += 1
 
-    def ema_from(self, other, beta):
-        """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch."""
+    def ema_from(self, other, beta, skip_flag=None):
+        """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch (a no-op while the device word
+        skip_flag is non-zero)."""
         assert self.params.numel() == other.params.numel()
-        ops.ema_update(self.params, other.params, beta)
+        if skip_flag is not None:
+            ops.ema_update_gated(self.params, other.params, beta, skip_flag)
+        else:
+            ops.ema_update(self.params, other.params, beta)
         ops.cast_bf16(self.params, self.params_bf16)
         engine.WEIGHT_EPOCH[0] += 1
+
+
+def merge_optim_state_dicts(*sds):
+    """Concatenate torch-style optimiser state dicts whose parameter indices already follow one another (optim_state_dict's index_base):
+    the dictionary `torch.optim.AdamW(groups_a + groups_b + ...).state_dict()` would hold."""
+    out = {"state": {}, "param_groups": []}
+    for sd in sds:
+        out["state"].update(sd["state"])
+        out["param_groups"] += sd["param_groups"]
+    return out
+
+
+def _empty_groups(lr, wd, betas=(0.9, 0.999), eps=1e-8):
+    """The two (empty) groups get_param_groups yields for a parameter-free predictor (BarlowTwinsPredictor(use=False) is an Identity)."""
+    g = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=wd, amsgrad=False, maximize=False, foreach=None, capturable=False,
+              differentiable=False, fused=None, params=[]) for _ in range(2)]
+    g[1]["weight_decay"] = 0.0
+    return {"state": {}, "param_groups": g}
 
 
 class GradSync:
@@ -177,7 +237,7 @@ class GradSync:
         self._ready_ranges = []
 
     def block_done(self, params):
-        """engine.BLOCK_DONE_HOOK: the gradients of `params` are final -> reduce their flat range now."""
+        """engine.block_done_hook(p) of this flat state: the gradients of `params` are final -> reduce their flat range now."""
         if not self.active:
             return
         spans = []
@@ -255,13 +315,12 @@ class BarlowTwinsTrainer:
         self.flat = FlatState(list(self.online.named_parameters()), device)
         self.criterion = BarlowTwinsLoss(cfg, ncrops=2).to(device)
         sdist.reserve_cus_for_collectives()
-        self.sync = GradSync(self.flat)
-        engine.BLOCK_DONE_HOOK = self.sync.block_done
+        self.sync = self.flat.sync = GradSync(self.flat)
         self.predictor = self.target = self.flat_pred = self.flat_target = None
         if mode == "byol":
             self.predictor = BarlowTwinsPredictor(cfg.projector_out_dim, use=True).to(device)
             self.flat_pred = FlatState(list(self.predictor.named_parameters()), device)
-            self.sync_pred = GradSync(self.flat_pred)
+            self.sync_pred = self.flat_pred.sync = GradSync(self.flat_pred)
             self.target = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
             self.target.load_state_dict(self.online.state_dict())
             for p in self.target.parameters():
@@ -275,6 +334,15 @@ class BarlowTwinsTrainer:
                                           cfg.mixup_ratio, virtual_crop_scale=tuple(cfg.virtual_crop_scale), seed=seed + 1000 * sdist.get_rank())
         self.post_norm = NormalizeBatch() if cfg.post_norm else None
         self.lr, self.wd = cfg.lr, cfg.wd
+        # What `optimizer.param_groups` is to the reference's loop: utils.adjust_learning_rate(args, trainer, loader, iteration) --
+        # main.py:52's call with this object in the optimiser's place -- writes the step's learning rates here, in get_optimizer's group
+        # order (encoder decayed / un-decayed, then the predictor's two groups); the fused AdamW launches read them.
+        self.param_groups = [{"lr": cfg.lr, "weight_decay": cfg.wd}, {"lr": cfg.lr, "weight_decay": 0.0}]
+        if mode == "byol":
+            self.param_groups += [{"lr": cfg.lr, "weight_decay": cfg.wd}, {"lr": cfg.lr, "weight_decay": 0.0}]
+        self._graph = self._graph_views = self._graph_loss = None
+        self.use_graph = True                            # False: run eagerly although a graph exists (profiling passes with per-launch events)
+        self.mask_ratio_schedule = None                  # per-iteration table (utils.sine_scheduler_increase, main.py:442), or None
         self.last_loss = None
         # main_bt_byol.py:116-118 stops on a non-finite loss with a host sync every step; here the test is a device-side counter that
         # the host reads every `finite_check_every` steps (and whenever assert_finite() is called)
@@ -291,18 +359,75 @@ class BarlowTwinsTrainer:
             self.frontend(batch, crop_frames=self.cfg.crop_frames, start=0, norm_stats=AUDIOSET_STATS, out=slots.view(B, 1, *slots.shape[1:]))
         else:
             slots.copy_(batch.view(B, *batch.shape[-2:]))
-        views = self.augment(B)
+        out = None
+        if self._graph is not None and self.use_graph and self.post_norm is None and self._graph_views[0].shape[0] == B:
+            out = self._graph_out()                          # the captured step's input buffers: the augmentation writes them in place
+        views = self.augment(B, out=out)
         v1, v2 = views[0], views[1]
         if self.post_norm is not None:
             v1, v2 = self.post_norm(v1), self.post_norm(v2)
         return [v1, v2]
 
-    # ------------------------------------------------------------------ one optimisation step
-    def step(self, batch):
-        return self.step_views(self.make_views(batch))
+    def _graph_out(self):
+        """[2, B, 1, F, T] tensor aliasing the two static view buffers when they are adjacent in memory (enable_graph allocates them so)."""
+        return self._graph_pair
 
-    def step_views(self, views):
-        """One optimisation step on two already-augmented views [B,1,F,T] (what train_one_epoch receives from its loader)."""
+    # ------------------------------------------------------------------ one optimisation step
+    def step(self, batch, iteration=None, loader_len=None, mask_ratio=None):
+        """One optimisation step on a batch.  With `iteration` (the global training iteration, main.py:48) the per-iteration schedules of
+        the reference's loop apply first: the learning rate (utils.adjust_learning_rate when cfg.lr_schedule, main.py:51-57; needs
+        loader_len = iterations per epoch) and, in mode 'mae', the mask ratio (mask_ratio_for, main.py:71-81)."""
+        if iteration is not None:
+            self.apply_schedules(iteration, loader_len)
+            if mask_ratio is None and self.mode == "mae":
+                mask_ratio = self.mask_ratio_for(iteration)
+        return self.step_views(self.make_views(batch), mask_ratio=mask_ratio)
+
+    def apply_schedules(self, iteration, loader_len):
+        """main.py:51-57: `if args.lr_schedule: utils.adjust_learning_rate(args, optimizer, data_loader, iteration)`."""
+        from . import utils
+        if getattr(self.cfg, "lr_schedule", False):
+            if loader_len is None:
+                raise ValueError("the learning-rate schedule needs loader_len (iterations per epoch)")
+            utils.adjust_learning_rate(self.cfg, self, range(loader_len), iteration)
+
+    def mask_ratio_for(self, iteration):
+        """The mask ratio main.py:71-81 picks for an iteration: the schedule table's entry, else (cfg.random_mask_ratio) 0 with
+        probability 1/2 and U(0.05, cfg.mask_beta) otherwise, else cfg.mask_ratio; 0 when cfg.mask is off."""
+        from . import utils
+        if not getattr(self.cfg, "mask", True):
+            return 0
+        if self.mask_ratio_schedule is not None:
+            return float(self.mask_ratio_schedule[iteration])
+        if getattr(self.cfg, "random_mask_ratio", False):
+            return utils.generate_random(l=0.05, h=self.cfg.mask_beta, p=0.5)
+        return self.cfg.mask_ratio
+
+    def step_views(self, views, mask_ratio=None):
+        """One optimisation step on two already-augmented views [B,1,F,T] (what train_one_epoch receives from its loader).  mask_ratio
+        (mode 'mae'): this step's masking ratio, cfg.mask_ratio when None.
+
+        The step is a host prologue (step counts, learning rates -> device, `stage`) followed by a device-only body (`_device_step`):
+        forward, loss, backward, gradient all-reduce, AdamW [, EMA].  With `enable_graph()` the body is captured once into a HIP graph
+        and replayed; the views are then copied into the graph's static input buffers."""
+        g = self.param_groups
+        self.flat.stage_hyper(g[0]["lr"], lr_nodecay=g[1]["lr"])
+        if self.mode == "byol":
+            self.flat_pred.stage_hyper(g[2]["lr"], lr_nodecay=g[3]["lr"])
+        if self._graph is not None and self.use_graph and mask_ratio is None:
+            for dst, src in zip(self._graph_views, views):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            self._graph.replay()
+        else:
+            self.last_loss = self._device_step(views, mask_ratio)
+        self._steps += 1
+        if self._steps % self.finite_check_every == 0:
+            self.assert_finite()
+        return self.last_loss
+
+    def _device_step(self, views, mask_ratio=None):
+        """Everything of a step that runs on the device, with no host-side state that changes from step to step (capturable)."""
         self.flat.zero_grad()
         engine.reset_pending_backward()
         if self.mode == "bt":
@@ -310,7 +435,7 @@ class BarlowTwinsTrainer:
             z1, z2 = z.chunk(2)
             loss = self.criterion.forward_loss(z1, z2)
         elif self.mode == "mae":
-            t, recon = self.online(views[:1], ncrops=1, mask_ratio=self.cfg.mask_ratio, masked_recon=True)
+            t, recon = self.online(views[:1], ncrops=1, mask_ratio=self.cfg.mask_ratio if mask_ratio is None else mask_ratio, masked_recon=True)
             st = self.online(views[1:], ncrops=1)
             loss = self.criterion(st, t, ngcrops_each=1) + recon
         else:
@@ -320,29 +445,71 @@ class BarlowTwinsTrainer:
             with torch.no_grad():
                 t = self.target(views, ncrops=2)
             loss = self.criterion(o, t, ngcrops_each=2)
-            self.flat_target.ema_from(self.flat, self.ema_beta)      # before the optimiser step (main_bt_byol.py:121-126)
         ops.count_nonfinite(loss.detach().reshape(1), self._nonfinite)
+        if self.mode == "byol":
+            # before the optimiser step (main_bt_byol.py:121-126); behind the finite-loss gate like the optimiser (:116-118)
+            self.flat_target.ema_from(self.flat, self.ema_beta, skip_flag=self._nonfinite)
         loss.backward()
         self.sync.finish()
-        self.flat.adamw(self.lr, self.wd)
+        # a non-finite loss (counted just above) turns the optimiser launches into no-ops: the reference exits before optimizer.step()
+        # (main_bt_byol.py:116-118); here the host reads the counter lazily, so the weights and moments are kept clean on the device
+        self.flat.adamw_staged(self.wd, skip_flag=self._nonfinite)
         if self.mode == "byol":
             self.sync_pred.finish()
-            self.flat_pred.adamw(self.lr, self.wd)
-        self.last_loss = loss.detach()
-        self._steps += 1
-        if self._steps % self.finite_check_every == 0:
-            self.assert_finite()
-        return self.last_loss
+            self.flat_pred.adamw_staged(self.wd, skip_flag=self._nonfinite)
+        return loss.detach()
+
+    # ------------------------------------------------------------------ HIP graph
+    def enable_graph(self, views=None):
+        """Capture `_device_step` (encoder + projector forward, loss, backward, gradient all-reduce, AdamW [, EMA]) into ONE HIP graph that
+        every later `step_views` / `step` replays: ~600 launches and ~150 allocator calls per step leave the host's critical path.  Call
+        after at least one eager step (workspaces sized, transposed weight copies allocated, BatchNorm buffers touched).  What changes from
+        step to step reaches the graph through device memory only: the views (static buffers, filled by the augmentation launch or a
+        copy), the learning rates and Adam bias corrections (FlatState.hyper), the non-finite gate.  Host-sampled augmentation
+        parameters, the frontend and the augmentation launch stay outside the graph.  Any failure of the capture raises -- there is no
+        silent eager fallback."""
+        if self._graph is not None:
+            return
+        if self._steps < 1:
+            raise RuntimeError("enable_graph(): run at least one eager step first (workspaces and weight copies are allocated lazily)")
+        if self.mode == "mae":
+            raise NotImplementedError("graph capture of mode 'mae' is not supported: its random masking draws from the host-visible generator")
+        pair = torch.empty(2, self.B, 1, self.cfg.n_mels, self.cfg.crop_frames, device=self.device)
+        if views is not None:
+            pair[0].copy_(views[0]); pair[1].copy_(views[1])
+        self._graph_pair = pair
+        self._graph_views = [pair[0], pair[1]]
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._graph_loss = self._device_step(self._graph_views)
+        self.last_loss = self._graph_loss
+        self._graph = graph
+        # the capture itself launched nothing; the host-side bookkeeping it advanced (weight epoch) describes the replayed step too
 
     # ------------------------------------------------------------------ checkpoint / resume
-    def state_dict(self, epoch=0):
+    def state_dict(self, epoch=0, driver="main_bt_byol"):
         """The dictionary main_bt_byol.py:492-498 saves ('model', 'optimizer', 'epoch', 'barlow_twins_loss'; the reference's drop of the
-        predictor / target there is SURVEY.md A.5's quirk -- they are included here so that a byol run resumes exactly)."""
-        sd = {"model": self.online.state_dict(), "optimizer": self.flat.optim_state_dict(self.lr, self.wd), "epoch": epoch,
+        predictor / target there is SURVEY.md A.5's quirk -- they are included here so that a byol run resumes exactly).
+
+        'optimizer' is what the reference driver's own optimiser would save: get_optimizer (main_bt_byol.py:301-305) builds ONE AdamW over
+        get_param_groups(encoder) + get_param_groups(predictor) -- four groups, the last two empty without a predictor -- and
+        `driver="main"` gives main.py's two-group form.  Refuses to save after a non-finite loss (the reference stops before the optimiser
+        step, main_bt_byol.py:116-118; here the flag is read lazily, so it is read now)."""
+        self.assert_finite()
+        opt = self.flat.optim_state_dict(self.lr, self.wd)
+        if driver == "main_bt_byol":
+            n_enc = sum(len(g["params"]) for g in opt["param_groups"])
+            pred = self.flat_pred.optim_state_dict(self.lr, self.wd, index_base=n_enc) if self.mode == "byol" else _empty_groups(self.lr, self.wd)
+            opt = merge_optim_state_dicts(opt, pred)
+        elif self.mode == "byol":
+            raise ValueError("driver='main' has no predictor; a byol trainer saves main_bt_byol.py's form")
+        for saved, live in zip(opt["param_groups"], self.param_groups):       # the learning rates the schedule last set
+            saved["lr"] = live["lr"]
+        sd = {"model": self.online.state_dict(), "optimizer": opt, "epoch": epoch,
               "barlow_twins_loss": self.criterion.state_dict(), "steps": self._steps}
         if self.mode == "byol":
             sd["predictor"] = self.predictor.state_dict()
-            sd["optimizer_predictor"] = self.flat_pred.optim_state_dict(self.lr, self.wd)
             sd["target"] = self.target.state_dict()
         return sd
 
@@ -352,15 +519,27 @@ class BarlowTwinsTrainer:
         strip = lambda sd: {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.online.load_state_dict(strip(ckpt["model"]))
         self.flat.refresh_from_parameters()
-        if "optimizer" in ckpt:
-            self.flat.load_optim_state_dict(ckpt["optimizer"])
+        opt = ckpt.get("optimizer")
+        if opt is not None:
+            if len(opt["param_groups"]) not in (2, 4):
+                raise ValueError(f"optimizer state with {len(opt['param_groups'])} parameter groups: expected main.py's 2 (encoder) or "
+                                 "main_bt_byol.py's 4 (encoder + predictor, --stop_gradient)")
+            self.flat.load_optim_state_dict(opt, 0)
+            if len(opt["param_groups"]) == 4:
+                n_pred = len(opt["param_groups"][2]["params"]) + len(opt["param_groups"][3]["params"])
+                if self.mode == "byol":
+                    self.flat_pred.load_optim_state_dict(opt, 2)
+                elif n_pred:
+                    raise ValueError(f"the checkpoint's optimizer holds {n_pred} predictor parameters; this trainer (mode '{self.mode}') has no predictor")
+            for live, saved in zip(self.param_groups, opt["param_groups"]):
+                live["lr"] = saved["lr"]
         if "barlow_twins_loss" in ckpt:
             self.criterion.load_state_dict(ckpt["barlow_twins_loss"])
         if self.mode == "byol":
             if "predictor" in ckpt:
                 self.predictor.load_state_dict(strip(ckpt["predictor"]))
                 self.flat_pred.refresh_from_parameters()
-            if "optimizer_predictor" in ckpt:
+            if "optimizer_predictor" in ckpt:                      # (round-2 checkpoints kept the predictor's moments under their own key)
                 self.flat_pred.load_optim_state_dict(ckpt["optimizer_predictor"])
             self.target.load_state_dict(strip(ckpt["target"]) if "target" in ckpt else self.online.state_dict())
             self.flat_target.refresh_from_parameters()
@@ -391,6 +570,7 @@ class _FrozenFlat:
             engine.BF16_WEIGHTS.pin(p, w.view(p.shape[0], -1) if p.dim() > 1 else w)
             if name in like.qkv_fused:
                 engine.QKV_BIAS[id(p)] = (weakref.ref(p), self.params[off:off + 3 * n])
+                engine._forget_when_dead(p, engine.QKV_BIAS)
         ops.cast_bf16(self.params, self.params_bf16)
 
     ema_from = FlatState.ema_from

@@ -143,6 +143,16 @@ class LARS(torch.optim.Optimizer):
                 BF16_WEIGHTS.mark_modified(p)
 
 
+def generate_random(l, h, p):
+    """`utils.generate_random` (utils/utils.py:30-33, main.py:76): with probability p the mask ratio is 0, otherwise U(l, h).  One
+    draw from Python's `random` decides, and only the non-zero branch consumes a draw from numpy's global generator -- the call order
+    a seeded reference run has."""
+    import random
+    import numpy as np
+    keep_zero = not (random.random() > p)
+    return 0 if keep_zero else np.random.uniform(l, h)
+
+
 def adjust_learning_rate(args, optimizer, loader, step):
     """`utils.adjust_learning_rate` (utils/utils.py:47-65, used by main.py:52): linear warm-up over epochs // 100 epochs, then a
     cosine from base to base / 1000 stretched over 1.25 x the run; base = batch_size / 128 and the result multiplies args.lr

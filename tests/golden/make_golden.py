@@ -645,6 +645,69 @@ def gen_resnet():
     save("resnet", **out)
 
 
+def gen_bn_eval():
+    """Eval mode of the BatchNorm2d encoders (`model.eval()`: running statistics, buffers untouched) -- the HEAR / linear-probe path.
+    ConvStem ViTC micro encoder (16x8 patches) and both ResNet-18 variants: one train-mode forward first, so the running buffers are
+    not their initial 0 / 1, then eval on a second batch.  Stored: every buffer after the train forward, the eval input and output."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import resnet as oresnet
+    from models import resnet as ref_resnet
+    out = {}
+    torch.manual_seed(0)
+    m = ref_mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 8], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                     norm_layer=partial(nn.LayerNorm, eps=1e-6), conv_stem=True)
+    perturb_(m, 4)
+    m.train()
+    torch.manual_seed(12)
+    m(torch.randn(3, 1, 64, 96) * 1.5 + 0.3)
+    m.eval()
+    for k, v in m.state_dict().items():
+        out["vitc_sd." + k] = t2n(v)
+    torch.manual_seed(13)
+    x = torch.randn(2, 1, 64, 96)
+    with torch.no_grad():
+        tok, _, _ = m.prepare_tokens(x, 0)
+        lat = m(x)
+    out["vitc_x"], out["vitc_tokens"], out["vitc_latent"] = t2n(x), t2n(tok), t2n(lat)
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert np.array_equal(t2n(v), out["vitc_sd." + k])            # eval left the buffers alone
+    for variant, ctor in [("resnet18", ref_resnet.resnet18), ("resnet18_ReGP_NRF", ref_resnet.resnet18_ReGP_NRF)]:
+        m = ctor()
+        m.fc = nn.Identity()
+        full = dict(oresnet.init_state(variant, seed=3, affine_seed=11))
+        for k in list(m.state_dict().keys()):
+            if k.endswith("num_batches_tracked"):
+                full[k] = torch.zeros((), dtype=torch.long)
+        m.load_state_dict(full, strict=True)
+        m.train()
+        torch.manual_seed(21)
+        m(torch.randn(4, 1, 64, 96) * 1.3 + 0.2)
+        m.eval()
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"{variant}.buf.{k}"] = t2n(v)
+        torch.manual_seed(22)
+        x = torch.randn(2, 1, 64, 96) * 1.3 + 0.2
+        with torch.no_grad():
+            y = m(x)
+        out[f"{variant}.x"], out[f"{variant}.y"] = t2n(x), t2n(y)
+        out[f"{variant}.affine_seed"] = np.array([3, 11])
+    save("bn_eval", **out)
+
+
+def gen_schedule():
+    """The per-iteration choices of main.py's loop: `generate_random` (utils/utils.py:30-33) over a seeded sequence of calls (the Python
+    and numpy global generators both seeded, as a seeded run has them), and the mask-ratio table main.py:440-448 builds."""
+    out = {}
+    random.seed(5)
+    np.random.seed(5)
+    out["rand_mask_ratio"] = np.array([float(ref_utils.generate_random(l=0.05, h=0.3, p=0.5)) for _ in range(64)])
+    out["rand_after"] = np.array([random.random(), np.random.uniform()])             # both generators' positions after the calls
+    out["mask_table"] = ref_utils.sine_scheduler_increase(final_value=0.3, epochs=10, niter_per_ep=7, warmup_epochs=int(10 / 5), warmup_value=0)
+    save("schedule", **out)
+
+
 def gen_hear():
     """HEAR wrapper (hear/sample/vit.py:40-247, hear/utils.py) run as the reference runs it: `ViTModelWrapper` + `get_scene_embeddings` /
     `get_timestamp_embeddings` on two 1.3 s clips.  Two absent third-party names are stood in for: `easydict.EasyDict` (attribute dict)
@@ -708,6 +771,8 @@ if __name__ == "__main__":
     gen_resnet() if "resnet" in sys.argv[1:] else None
     gen_convstem() if "convstem" in sys.argv[1:] else None
     gen_audiontt() if "audiontt" in sys.argv[1:] else None
+    gen_bn_eval() if "bn_eval" in sys.argv[1:] else None
+    gen_schedule() if "schedule" in sys.argv[1:] else None
     if len(sys.argv) > 1:
         sys.exit(0)
     gen_bt_loss()

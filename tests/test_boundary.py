@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in syms if not hasattr(h, s)]
     assert not missing, missing
     h.sa_abi_version.restype = ctypes.c_int
-    assert h.sa_abi_version() == 3
+    assert h.sa_abi_version() == 4
     # every declared function has ctypes argument types (a missing entry would silently pass ints as 32-bit)
     assert [s for s in syms if s not in _lib._SIGNATURES and s != "sa_last_error"] == []
 
@@ -207,3 +207,27 @@ def test_driver_import_block_resolves_through_the_shims():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "amd_shims"), ROOT]))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_custom_ops_cover_every_compute_entry_point():
+    """`torch.ops.ssl_audio.*` (ssl_audio_amd/custom_ops.py): one registered operator per compute entry point of the header -- only the
+    queries (version, error string, device info, workspace sizes, CU budget) stay plain C calls -- with a parsed schema that marks the
+    written tensors, and no CPU implementation (the dispatcher refuses CPU tensors: there is no fallback)."""
+    import inspect
+    import torch
+    from ssl_audio_amd import _lib, custom_ops, ops
+    covered = {sym for sym, _ in custom_ops.SCHEMAS.values()}
+    plain = {s for s in _lib.header_symbols() if s not in covered}
+    assert plain == {"sa_abi_version", "sa_last_error", "sa_device_info", "sa_set_cu_budget", "sa_bn_tall_workspace_bytes",
+                     "sa_gemm_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes"}, plain
+    assert covered <= set(_lib.header_symbols())
+    for name, (sym, schema) in custom_ops.SCHEMAS.items():
+        op = getattr(torch.ops.ssl_audio, name).default
+        sch = op._schema
+        assert any(a.alias_info is not None and a.alias_info.is_write for a in sch.arguments), name      # every operator writes an argument
+        assert len(sch.returns) == 0, name
+        assert [a.name for a in sch.arguments] == list(inspect.signature(getattr(ops, name)).parameters), name
+        src = inspect.getsource(getattr(ops, name))
+        assert f"lib().{sym}(" in src, (name, sym)                                                           # ... and reaches the symbol it names
+    with pytest.raises(NotImplementedError):
+        torch.ops.ssl_audio.axpy(torch.zeros(4), torch.ones(4), 2.0)

@@ -278,3 +278,54 @@ def test_full_size_properties(dev, name, model_type, frames, B, mode):
     assert torch.equal(tr.flat.params_bf16.float(), tr.flat.params.to(torch.bfloat16).float())
     del tr
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["bt", "byol"])
+def test_graph_replay_equals_eager(dev, mode):
+    """the device part of the step captured into ONE HIP graph (BarlowTwinsTrainer.enable_graph) and replayed takes the
+    same steps as the eager path: same losses and the same weights / Adam moments / EMA target after four steps, with the learning rate
+    CHANGING between steps (it reaches the captured AdamW launches through device memory) -- agreement to fp32 summation-order noise
+    (the bias-gradient column sums use atomics), far below one bf16 ulp of any weight."""
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       stop_gradient=(mode == "byol"), predictor=(mode == "byol"))
+    g = torch.Generator().manual_seed(4)
+    base = [torch.randn(8, 1, 64, 96, generator=g) for _ in range(5)]
+    batches = [[(b + 0.3 * torch.randn(8, 1, 64, 96, generator=g)).to(dev), (b + 0.3 * torch.randn(8, 1, 64, 96, generator=g)).to(dev)] for b in base]
+    lrs = [1e-4, 3e-4, 2e-4, 5e-5, 1e-4]
+
+    def run(graph):
+        tr = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
+        losses = []
+        for i, v in enumerate(batches):
+            for grp in tr.param_groups:
+                grp["lr"] = lrs[i]
+            losses.append(float(tr.step_views(v)))
+            if i == 0 and graph:
+                tr.enable_graph()
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        return tr, losses
+
+    a, la = run(False)
+    b, lb = run(True)
+    print(mode, "eager losses", la, "graph losses", lb)
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-5 * abs(x), (la, lb)
+    assert a.flat.step_count == b.flat.step_count == 5
+    for name in ("params", "m", "v"):
+        ta, tb = getattr(a.flat, name), getattr(b.flat, name)
+        assert float((ta - tb).abs().max()) <= 2e-3 * float(ta.abs().max()) and float((ta - tb).norm() / ta.norm()) < 1e-3, name
+    # the moved-by-lr structure: a wrong (stale) learning rate or bias correction inside the graph would shift every weight by O(lr)
+    moved = float((a.flat.params - b.flat.params).abs().max())
+    assert moved <= 0.3 * min(lrs), moved
+    if mode == "byol":
+        assert float((a.flat_target.params - b.flat_target.params).abs().max()) <= 0.3 * min(lrs)
+        assert float((a.flat_pred.params - b.flat_pred.params).abs().max()) <= 0.3 * min(lrs)
+    # a non-finite loss leaves weights and moments untouched (device-side gate), and the host notices on its next look
+    before = b.flat.params.clone(), b.flat.m.clone()
+    bad = [torch.full_like(batches[0][0], float("nan")), batches[0][1]]
+    b.step_views(bad)
+    torch.cuda.synchronize()
+    assert torch.equal(b.flat.params, before[0]) and torch.equal(b.flat.m, before[1])
+    with pytest.raises(FloatingPointError):
+        b.assert_finite()

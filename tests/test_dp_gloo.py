@@ -139,7 +139,7 @@ def _worker_body(rank, world, port, q):
     params = [torch.nn.Parameter(torch.zeros(10)) for _ in range(3)]
     for k, p in enumerate(params):                          # three "block" parameters living at [20,30), [30,40), [60,70)
         off = [20, 30, 60][k]
-        engine.GRAD_SINK[id(p)] = (weakref.ref(p), flat.grads[off:off + 10])
+        engine.register_grad_sink(p, flat.grads[off:off + 10], flat)
     sync = GradSync(flat)
     sync.block_done(params[:2])                             # one contiguous run [20, 40)
     sync.block_done([params[2], params[0]])                 # scattered: [60, 70) and (again, idempotent ranges are NOT allowed) -> see below
@@ -150,12 +150,17 @@ def _worker_body(rank, world, port, q):
     flat2.n_train = 96
     flat2.grads = torch.zeros(96)
     q0, q1 = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
-    engine.GRAD_SINK[id(q0)] = (weakref.ref(q0), flat2.grads[0:8])
-    engine.GRAD_SINK[id(q1)] = (weakref.ref(q1), flat2.grads[80:88])
+    engine.register_grad_sink(q0, flat2.grads[0:8], flat2)
+    engine.register_grad_sink(q1, flat2.grads[80:88], flat2)
     flat2.grads[0:8] = rank + 1.0
     flat2.grads[80:88] = 10.0 * (rank + 1)
-    sync2 = GradSync(flat2)
-    sync2.block_done([q0, q1])
+    sync2 = flat2.sync = GradSync(flat2)
+    # hooks are instance state: each parameter's block hook is the GradSync of the flat buffer that holds ITS sink, so two live
+    # trainers never reduce each other's ranges (the process-global engine.BLOCK_DONE_HOOK)
+    flat.sync = sync
+    assert engine.block_done_hook(q0).__self__ is sync2 and engine.block_done_hook(params[0]).__self__ is sync
+    assert engine.block_done_hook(torch.nn.Parameter(torch.zeros(3))) is None
+    engine.block_done_hook(q0)([q0, q1])
     flat2.grads[8:80] = 100.0 * (rank + 1)                  # "later layers" finish after the hook fired
     sync2.finish()
     tot = sum(range(1, world + 1))

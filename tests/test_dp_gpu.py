@@ -221,7 +221,46 @@ def _resnet_step(rank, world):
     return float(loss.detach()), {k: sd[k].detach().float().cpu().numpy() for k in RESNET_KEYS}, grads, p0, lr
 
 
-_STEPS = {"dropin": _dropin_step, "mae": _mae_step, "resnet": _resnet_step}
+def _byol_step(rank, world):
+    """trainer mode 'byol' (BASELINE config 4, main_bt_byol.py --stop_gradient --predictor): TWO GradSync objects (encoder + projector
+    flat state, predictor flat state), the frozen EMA target in a _FrozenFlat with the online layout, the flat EMA launch before the
+    optimiser step.  A second, idle trainer is alive in the same process: block hooks are instance state (engine.block_done_hook), so
+    its flat buffers must stay untouched by the first one's backward."""
+    from ssl_audio_amd import hyperparameters as hp
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    dev = torch.device("cuda:0")
+    Bg = 16
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=Bg, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
+                       stop_gradient=True, predictor=True)
+    tr = BarlowTwinsTrainer(cfg, dev, mode="byol", batch_per_rank=Bg // world, clip_samples=15200, seed=0, from_waveform=False)
+    other = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=Bg // world, clip_samples=15200, seed=5, from_waveform=False)   # built LAST
+    other.flat.grads.fill_(3.0)
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(Bg, 1, 64, 96, generator=g)
+    views = [base + 0.3 * torch.randn(Bg, 1, 64, 96, generator=g), base + 0.3 * torch.randn(Bg, 1, 64, 96, generator=g)]
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    p0 = {k: v.detach().float().cpu().numpy().copy() for k, v in tr.online.state_dict().items() if k in KEYS}
+    t0 = tr.flat_target.params.clone()
+    loss = float(tr.step_views([v[sl].to(dev).contiguous() for v in views]))
+    torch.cuda.synchronize()
+    assert bool((other.flat.grads == 3.0).all()), "the idle trainer's gradient buffer was reduced by the active trainer's hooks"
+    grads = _grads(tr)
+    off, n = tr.flat_pred.offsets["predictor.0.weight"]
+    grads["predictor.0.weight"] = tr.flat_pred.grads[off:off + n].detach().float().cpu().numpy().copy()
+    sd = tr.online.state_dict()
+    out = {k: sd[k].detach().float().cpu().numpy() for k in KEYS}
+    # the EMA target moved by (1 - beta) * (online_before - target_before) = 0 on the first step (target == online) -- so compare the
+    # target after a SECOND step, where online has moved: target = 0.99 target + 0.01 online_after_step_1
+    loss2 = float(tr.step_views([v[sl].to(dev).contiguous() for v in views]))
+    torch.cuda.synchronize()
+    o2, n2 = tr.flat.offsets["head.projector.3.weight"]
+    out["target.head.projector.3.weight"] = tr.flat_target.params[o2:o2 + n2].detach().float().cpu().numpy().copy()
+    p0["target.head.projector.3.weight"] = t0[o2:o2 + n2].float().cpu().numpy().copy()
+    assert np.isfinite(loss2)
+    return loss, out, grads, p0, tr.lr
+
+
+_STEPS = {"dropin": _dropin_step, "mae": _mae_step, "resnet": _resnet_step, "byol": _byol_step}
 
 
 def _worker2(kind, rank, world, port, q):
@@ -240,10 +279,10 @@ def _worker2(kind, rank, world, port, q):
         q.put((rank, repr(e) + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("kind", ["dropin", "mae", "resnet"])
+@pytest.mark.parametrize("kind", ["dropin", "mae", "resnet", "byol"])
 def test_two_ranks_equal_single_process_other_flows(kind):
     """(dropin) the reference driver's own loop on the drop-in classes, wrapped by utils.model_setup_ddp, torch.optim.AdamW;
-    (mae) trainer mode 'mae'.  Two ranks with half of the batch each == one process on the whole batch: same loss, summed
+    (mae) trainer mode 'mae'; (byol) trainer mode 'byol' next to a second live trainer.  Two ranks with half of the batch each == one process on the whole batch: same loss, summed
     gradients equal the single-process gradients (3e-2: bf16 partial sums in another order), replicas bit-identical."""
     world = 2
     ctx = mp.get_context("spawn")
@@ -272,7 +311,10 @@ def test_two_ranks_equal_single_process_other_flows(kind):
     assert abs(res[0][2] - res[1][2]) < 1e-6 * abs(loss) + 1e-6
     for k in res[0][3]:
         np.testing.assert_array_equal(res[0][3][k], res[1][3][k])        # replicas stay bit-identical across ranks
-        if "running" in k:                                               # SyncBN: the buffers are those of the global batch
+        if k.startswith("target."):                                      # EMA target after two steps: 0.99 * target + 0.01 * online, on every rank
+            moved = np.abs(sd[k] - p0[k]).max()
+            assert 0 < moved <= 0.0101 * lr + 1e-7, (k, moved)        # (+ fp32 rounding of the weights themselves)
+        elif "running" in k:                                             # SyncBN: the buffers are those of the global batch
             assert np.linalg.norm(res[0][3][k] - sd[k]) <= 2e-2 * np.linalg.norm(sd[k]) + 1e-6, k
         else:
             moved = np.abs(sd[k] - p0[k]).max()

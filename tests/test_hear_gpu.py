@@ -120,6 +120,9 @@ def test_trainer_checkpoint_resume(dev, mode):
     a = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
     for v in batches[:2]:
         a.step_views(v)
+    a_main_form = a.state_dict(driver="main")["optimizer"] if mode != "byol" else None
+    a_m_before, a_v_before = a.flat.m.clone(), a.flat.v.clone()
+    a_pm_before = a.flat_pred.m.clone() if mode == "byol" else None
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "ckpt.pth")
         utils.save_on_master(a.state_dict(epoch=3), path)
@@ -131,11 +134,36 @@ def test_trainer_checkpoint_resume(dev, mode):
     la, lb = float(a.step_views(batches[2])), float(b.step_views(batches[2]))
     assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
     assert rel(b.flat.params, a.flat.params.cpu()) < 1e-6
-    # the optimizer entry in the reference driver's optimiser
-    opt = torch.optim.AdamW(utils.get_param_groups(b.online), lr=cfg.lr, weight_decay=cfg.wd)
+    # the 'optimizer' entry in the reference driver's OWN optimiser, built the way get_optimizer builds it (main_bt_byol.py:301-305):
+    # one AdamW over get_param_groups(encoder) + get_param_groups(predictor) -- four groups, the last two empty without a predictor
+    from ssl_audio_amd.model import BarlowTwinsPredictor
+    pred_mod = b.predictor if mode == "byol" else BarlowTwinsPredictor(cfg.projector_out_dim, use=False)
+    groups = utils.get_param_groups(b.online)
+    groups.extend(utils.get_param_groups(pred_mod))
+    opt = torch.optim.AdamW(groups, lr=cfg.lr, weight_decay=cfg.wd)
     opt.load_state_dict(ckpt["optimizer"])
+    assert len(opt.param_groups) == 4 and opt.param_groups[1]["weight_decay"] == 0.0 and opt.param_groups[3]["weight_decay"] == 0.0
     p0 = opt.param_groups[0]["params"][0]
+    assert opt.state[p0]["exp_avg"].shape == p0.shape and int(float(opt.state[p0]["step"])) == 2
     name0 = [n for n, p in b.online.named_parameters() if p is p0][0]
     off, cnt = a.flat.offsets[name0]
-    assert opt.state[p0]["exp_avg"].shape == p0.shape and int(float(opt.state[p0]["step"])) == 2
-    assert len(opt.param_groups) == 2 and opt.param_groups[1]["weight_decay"] == 0.0
+    assert torch.equal(opt.state[p0]["exp_avg"].reshape(-1).to(dev), a_m_before[off:off + cnt])
+    if mode == "byol":
+        q0 = opt.param_groups[2]["params"][0]
+        qn = [n for n, p in b.predictor.named_parameters() if p is q0][0]
+        off, cnt = a.flat_pred.offsets[qn]
+        assert torch.equal(opt.state[q0]["exp_avg"].reshape(-1).to(dev), a_pm_before[off:off + cnt])
+    # ... and the reverse: what that optimiser saves (a real main_bt_byol.py checkpoint) resumes a trainer, predictor moments included
+    c = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=11, from_waveform=False)
+    ref_ckpt = {"model": ckpt["model"], "optimizer": opt.state_dict(), "epoch": 5, "barlow_twins_loss": ckpt["barlow_twins_loss"]}
+    if mode == "byol":
+        ref_ckpt.update(predictor=ckpt["predictor"], target=ckpt["target"])
+    assert c.load_state_dict(ref_ckpt) == 5 and c.flat.step_count == 2
+    assert torch.equal(c.flat.m, a_m_before) and torch.equal(c.flat.v, a_v_before)
+    if mode == "byol":
+        assert torch.equal(c.flat_pred.m, a_pm_before) and c.flat_pred.step_count == 2
+    else:                                                   # main.py's two-group optimiser state loads as well
+        opt2 = torch.optim.AdamW(utils.get_param_groups(b.online), lr=cfg.lr, weight_decay=cfg.wd)
+        opt2.load_state_dict(a_main_form)
+        c.load_state_dict({"model": ckpt["model"], "optimizer": opt2.state_dict()})
+        assert torch.equal(c.flat.m, a_m_before)

@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 from ssl_audio_amd import ops  # noqa: E402
 from ssl_audio_amd import frontend as fe  # noqa: E402
 
+BF16 = torch.bfloat16
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -591,3 +593,28 @@ def test_c_abi_launches_are_graph_capturable(dev):
         assert float(dw.abs().sum()) > 0
     finally:
         ops.DETERMINISTIC_WGRAD = old
+
+
+def test_custom_ops_reach_the_same_kernels(dev):
+    """torch.ops.ssl_audio.* (torch.library) against the direct ctypes route: same symbol, same bits -- GEMM with a fused epilogue,
+    LayerNorm forward, the fused AdamW step (in-place mutation visible through the dispatcher)."""
+    import ssl_audio_amd.custom_ops  # noqa: F401
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, N, K = 300, 192, 128
+    A = torch.randn(M, K, device=dev, generator=g).to(BF16); B = torch.randn(N, K, device=dev, generator=g).to(BF16)
+    bias = torch.randn(N, device=dev, generator=g); res = torch.randn(M, N, device=dev, generator=g)
+    o1, o2 = torch.empty(M, N, device=dev), torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(A, B, bias=bias, residual=res, out_f32=o1)
+    torch.ops.ssl_audio.gemm(A, B, bias=bias, residual=res, out_f32=o2)
+    assert torch.equal(o1, o2)
+    x = torch.randn(37, 768, device=dev, generator=g); w = torch.randn(768, device=dev, generator=g); b = torch.randn(768, device=dev, generator=g)
+    y1, y2 = torch.empty(37, 768, dtype=BF16, device=dev), torch.empty(37, 768, dtype=BF16, device=dev)
+    ops.layernorm_fwd(x, w, b, 1e-6, y_bf16=y1)
+    torch.ops.ssl_audio.layernorm_fwd(x, w, b, 1e-6, y_bf16=y2)
+    assert torch.equal(y1, y2)
+    p1 = torch.randn(4096, device=dev, generator=g); gr = torch.randn(4096, device=dev, generator=g)
+    p2, m1, v1, m2, v2 = p1.clone(), torch.zeros(4096, device=dev), torch.zeros(4096, device=dev), torch.zeros(4096, device=dev), torch.zeros(4096, device=dev)
+    ops.adamw_step(p1, gr, m1, v1, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1)
+    ver = p2._version
+    torch.ops.ssl_audio.adamw_step(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and p2._version > ver

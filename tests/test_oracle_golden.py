@@ -433,6 +433,62 @@ def test_resnet_oracle_matches_reference(golden, variant):
             assert np.allclose(0.9 + 0.1 * var.numpy() * cnt / (cnt - 1), g[f"{variant}.after.{name}.running_var"], rtol=1e-4, atol=1e-6), name
 
 
+def test_schedule_choices_golden(golden):
+    """main.py:51-57,71-81: utils.generate_random consumes the two global generators exactly like the reference (values AND generator
+    positions afterwards), and the trainer's mask_ratio_for / apply_schedules make the loop's choices (table entry, random draw,
+    constant; learning rates written into param_groups by utils.adjust_learning_rate with the trainer in the optimiser's place)."""
+    import random
+    import types
+    from ssl_audio_amd import utils
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    g = golden("schedule")
+    random.seed(5)
+    np.random.seed(5)
+    got = np.array([float(utils.generate_random(l=0.05, h=0.3, p=0.5)) for _ in range(64)])
+    np.testing.assert_array_equal(got, g["rand_mask_ratio"])
+    np.testing.assert_array_equal(np.array([random.random(), np.random.uniform()]), g["rand_after"])
+    assert (got == 0).any() and (got > 0.05).any()
+    table = utils.sine_scheduler_increase(final_value=0.3, epochs=10, niter_per_ep=7, warmup_epochs=2, warmup_value=0)
+    np.testing.assert_allclose(table, g["mask_table"], rtol=1e-12, atol=1e-15)
+    # the trainer's choices, without building a trainer (no GPU here): the methods only read cfg / param_groups
+    t = types.SimpleNamespace(cfg=types.SimpleNamespace(mask=True, random_mask_ratio=False, mask_ratio=0.75, mask_beta=0.3, lr_schedule=True,
+                                                        epochs=300, batch_size=256, lr=1e-4, optimizer="AdamW"),
+                              mask_ratio_schedule=None, param_groups=[{"lr": -1.0} for _ in range(4)])
+    assert BarlowTwinsTrainer.mask_ratio_for(t, 3) == 0.75
+    t.mask_ratio_schedule = table
+    assert BarlowTwinsTrainer.mask_ratio_for(t, 20) == float(g["mask_table"][20])
+    t.mask_ratio_schedule, t.cfg.random_mask_ratio = None, True
+    random.seed(5)
+    np.random.seed(5)
+    assert [float(BarlowTwinsTrainer.mask_ratio_for(t, i)) for i in range(8)] == list(g["rand_mask_ratio"][:8])
+    t.cfg.mask = False
+    assert BarlowTwinsTrainer.mask_ratio_for(t, 0) == 0
+    lr_rows = golden("optim")["adjust_lr_adamw"]                       # reference's adjust_learning_rate, 13 iterations per epoch
+    for row in lr_rows:
+        BarlowTwinsTrainer.apply_schedules(t, int(row[0]), 13)
+        assert all(abs(grp["lr"] - row[1]) <= 1e-12 * max(abs(row[1]), 1e-30) for grp in t.param_groups), row
+
+
+def test_bn_eval_oracle_matches_reference(golden):
+    """Eval mode of the BatchNorm2d encoders (running statistics): oracle == the reference's `model.eval()` forward on
+    tests/golden/bn_eval.npz (ConvStem ViTC micro encoder, both ResNet-18 variants)."""
+    from oracle import resnet as oresnet, vit as ovit
+    g = golden("bn_eval")
+    sd = {k[len("vitc_sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vitc_sd.")}
+    x = torch.from_numpy(g["vitc_x"])
+    tok, _, _ = ovit.prepare_tokens(x, sd, (4, 12), patch=(16, 8), bn_stats="eval")
+    lat = ovit.forward(x, sd, 2, (4, 12), patch=(16, 8), bn_stats="eval")
+    assert float((tok - torch.from_numpy(g["vitc_tokens"])).abs().max()) < 1e-5
+    assert float((lat - torch.from_numpy(g["vitc_latent"])).abs().max()) < 1e-5
+    for variant in ("resnet18", "resnet18_ReGP_NRF"):
+        seed, aseed = [int(v) for v in g[f"{variant}.affine_seed"]]
+        p = oresnet.init_state(variant, seed, aseed)
+        p.update({k[len(variant) + 5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"{variant}.buf.") and "running" in k})
+        y = oresnet.forward(torch.from_numpy(g[f"{variant}.x"]), p, variant, training=False)
+        ref = torch.from_numpy(g[f"{variant}.y"])
+        assert float((y - ref).norm() / ref.norm()) < 2e-5, variant
+
+
 def test_hear_oracle_matches_the_reference_wrapper(golden):
     """oracle/hear.py == hear/sample/vit.py + hear/utils.py as the reference ran them (tests/golden/hear.npz: the reference's wrapper with
     `torchaudio.transforms.MelSpectrogram` stood in for by oracle/frontend.py, so the mel arithmetic itself stays unpinned): the normalised

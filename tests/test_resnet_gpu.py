@@ -171,6 +171,102 @@ def test_resnet_golden(dev, variant):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 1
+@pytest.mark.parametrize("variant", ["resnet18", "resnet18_ReGP_NRF"])
+def test_resnet_eval_mode_golden(dev, variant):
+    """`net.eval()` = nn.BatchNorm2d on its RUNNING statistics (the reference's kNN / linear-eval / HEAR path): embedding against the
+    reference's eval forward (tests/golden/bn_eval.npz), every buffer untouched, and a clip's embedding independent of its batch."""
+    g = np.load(os.path.join(GOLD, "bn_eval.npz"))
+    seed, aseed = [int(v) for v in g[f"{variant}.affine_seed"]]
+    net, _ = load_net(variant, dev, seed, aseed)
+    bufs = {k[len(variant) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{variant}.buf.")}
+    net.load_state_dict(bufs, strict=False)
+    net.eval()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.from_numpy(g[f"{variant}.x"]).to(dev)
+    with torch.no_grad():
+        y = net(x)
+        y0 = net(x[:1])
+    e = rel(y, g[f"{variant}.y"])
+    print(f"{variant} eval: embedding rel {e:.2e} vs the reference")
+    assert e <= 3e-2, e
+    assert rel(y0, y[:1]) < 1e-6                                   # batch composition does not enter
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.parametrize("variant", ["resnet18", "resnet18_ReGP_NRF"])
+def test_resnet_eval_gradients_flat_bound(dev, variant):
+    """every ResNet-18 gradient with a FLAT bound.  In train mode 20 BatchNorm layers on batch statistics make
+    the gradients of a randomly initialised ResNet chaotic at ANY batch size (test below: the oracle's own fp32-vs-bf16 distance is
+    30-50 % at 32 clips as at 4), so the flat bound is asserted where the problem IS conditioned: `net.eval()`, BatchNorm as the fixed
+    affine map of the reference's running buffers (tests/golden/bn_eval.npz).  The same convolution / GEMM / col2im / pooling /
+    residual kernels run forward and backward; HIP-vs-mirror <= 2e-2 on all 62 parameters, HIP-vs-fp32 printed."""
+    from oracle import resnet as oresnet, rounding as R
+    g = np.load(os.path.join(GOLD, "bn_eval.npz"))
+    seed, aseed = [int(v) for v in g[f"{variant}.affine_seed"]]
+    net, sd = load_net(variant, dev, seed, aseed)
+    bufs = {k[len(variant) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{variant}.buf.")}
+    net.load_state_dict(bufs, strict=False)
+    net.eval()
+    sd = dict(sd, **{k: v for k, v in bufs.items() if "running" in k})
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(6, 1, 64, 96, generator=gen) * 1.3 + 0.2
+    y = net(x.to(dev))
+    w = torch.randn(y.shape, generator=gen)
+    (y * w.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()}
+
+    def oracle_grads():
+        p = {k: v.clone().requires_grad_("running" not in k) for k, v in sd.items()}
+        yo = oresnet.forward(x, p, variant, training=False)
+        (yo * w).sum().backward()
+        return {k: v.grad for k, v in p.items() if v.grad is not None}
+    fgrads = oracle_grads()
+    with R.mirror_hip_bf16():
+        mgrads = oracle_grads()
+    rows = {n: (rel(got[n], mgrads[n]), rel(got[n], fgrads[n]), rel(mgrads[n], fgrads[n])) for n in got}
+    worst = sorted(rows, key=lambda n: -rows[n][0])[:5]
+    for n in list(rows)[:3] + worst:
+        print(f"   {n:30s} HIP-vs-mirror {rows[n][0]:.4f}   HIP-vs-fp32 {rows[n][1]:.4f}   (mirror-vs-fp32 sensitivity {rows[n][2]:.4f})")
+    print(f"{variant} eval: {len(rows)} gradients; HIP-vs-mirror median {np.median([v[0] for v in rows.values()]):.4f} max {max(v[0] for v in rows.values()):.4f}; "
+          f"HIP-vs-fp32 max {max(v[1] for v in rows.values()):.4f}; sensitivity max {max(v[2] for v in rows.values()):.4f}")
+    assert len(rows) == 62
+    assert max(v[0] for v in rows.values()) <= 2e-2, {n: rows[n] for n in worst}
+    assert max(v[1] for v in rows.values()) <= 2e-1
+
+
+def test_resnet_train_gradients_are_chaotic_at_any_batch(dev):
+    """Why the train-mode ResNet gradient checks are sensitivity-relative (tests/gradcheck.py) and not flat: at 32 clips (192 rows in
+    the smallest BatchNorm, 49 152 in the stem) the oracle's own gradients still move by 30-50 % when it rounds where the HIP path
+    stores bf16 -- the same as at the fixture's 4 clips.  Printed for the log; asserted: the fixture really is that sensitive (else a
+    flat bound would be due), and HIP-vs-mirror stays inside the sensitivity-relative rule."""
+    from oracle import resnet as oresnet, rounding as R
+    variant = "resnet18"
+    net, sd = load_net(variant, dev, 3, 11)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(32, 1, 64, 96, generator=g) * 1.3 + 0.2
+    y = net(x.to(dev))
+    w = torch.randn(y.shape, generator=g)
+    (y * w.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()}
+
+    def oracle_grads():
+        p = {k: v.clone().requires_grad_("running" not in k) for k, v in sd.items()}
+        yo = oresnet.forward(x, p, variant)
+        (yo * w).sum().backward()
+        return {k: v.grad for k, v in p.items() if v.grad is not None}
+    fgrads = oracle_grads()
+    with R.mirror_hip_bf16():
+        mgrads = oracle_grads()
+    sens = [rel(mgrads[n], fgrads[n]) for n in got]
+    errs = [rel(got[n], mgrads[n]) for n in got]
+    print(f"resnet18 train, B=32: bf16 sensitivity (mirror-vs-fp32) median {np.median(sens):.4f} max {max(sens):.4f}; HIP-vs-mirror median {np.median(errs):.4f} max {max(errs):.4f}")
+    assert np.median(sens) > 0.1
+    check_step_gradients("resnet18 B=32", got, mgrads, fgrads, 55)
+
+
 def test_cfg1_resnet18_1s_b32_bt_step_vs_oracle(dev):
     """BASELINE config 1 (ResNet-18, 1 s synthetic clips -> 64 x 96 log-mel crops, batch 32, Barlow Twins; the reference's CPU-runnable
     case) as main.py:86-119 runs it, on the HIP path behind the reference's classes: embeddings by cosine, loss rel <= 3e-2 against the
