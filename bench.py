@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md: 6.29 TB/s meas
 
 
 def source_sha():
-    """Hash of the kernel sources: profiles/r02_gemm_traffic.json carries the hash it was collected at and is ignored when stale."""
+    """Hash of the kernel sources: profiles/r03_gemm_traffic.json carries the hash it was collected at and is ignored when stale."""
     import glob, hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.h"))):
@@ -132,7 +132,10 @@ def main():
     ap.add_argument("--workload", default="vit_base_bt_10s", choices=sorted(WORKLOADS))
     ap.add_argument("--batch_per_gpu", type=int, default=None)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_graph", action="store_true", help="run every step eagerly (default: the device part of the step is one HIP graph)")
+    ap.add_argument("--graph", action="store_true", help="replay the device part of the step as ONE HIP graph (BarlowTwinsTrainer.enable_graph); "
+                    "default eager: measured on MI355X / ROCm 7.2 the replay of the ~600-node graph is 1-2 % SLOWER than the eager launches, "
+                    "which already keep the GPU saturated (42.7 vs 43.3 ms per step)")
+    ap.add_argument("--no_graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--profile_steps", type=int, default=3, help="eager steps with per-launch HIP events after the timed region (roofline)")
     args = ap.parse_args()
 
@@ -187,15 +190,15 @@ def main():
         torch.cuda.synchronize()
 
     note(f"model + {2 * B} synthetic clips resident; warm-up x{args.warmup}")
-    use_graph = not args.no_graph and mode != "mae" and os.environ.get("SA_BENCH_GRAPH", "1") != "0"
+    use_graph = args.graph and not args.no_graph and mode != "mae"
     for i in range(max(args.warmup, 1)):
         trainer.step(pool[i % 2])
         torch.cuda.synchronize()
         note(f"warm-up step {i} done (loss {float(trainer.last_loss):.4f})")
         if i == 0 and use_graph:
-            # the device part of the step (forward, loss, backward, all-reduce, AdamW) becomes ONE HIP graph; the remaining warm-up steps
-            # replay it.  A failed capture is fatal for this process (no silent eager fallback): rank 0 of a single-GPU run hands over
-            # to a FRESH child process that runs eagerly (never a re-exec of a process that has touched the GPU).
+            # --graph: the device part of the step (forward, loss, backward, all-reduce, AdamW) becomes ONE HIP graph; the remaining warm-up
+            # steps replay it.  A failed capture is fatal for this process (no silent eager fallback): rank 0 of a single-GPU run hands
+            # over to a FRESH child process that runs eagerly (never a re-exec of a process that has touched the GPU).
             try:
                 trainer.enable_graph()
                 trainer.step(pool[1])                                  # first replay (untimed)
@@ -207,7 +210,7 @@ def main():
                     raise
                 import subprocess
                 os.dup2(real_stdout, 1)
-                child = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no_graph"])
+                child = subprocess.run([sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--graph"])
                 sys.exit(child.returncode)
     barrier()
     t0 = time.perf_counter()
@@ -258,16 +261,16 @@ def main():
         d_ms, d_fl, d_nb, d_n = by_kernel[dom]
         d_tflops = d_fl / (d_ms * 1e-3) / 1e12
         traffic, traffic_note = None, "no PMC summary for this workload"
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
         if os.path.exists(tpath) and args.workload == "vit_base_bt_10s" and B == 128:
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/collect_traffic.sh), valid
             # only for the kernel sources it was collected with
             tj = json.load(open(tpath))
             if tj.get("source_sha") == source_sha():
                 traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE) of this command, profiles/r02_gemm_traffic.json"
+                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE) of this command, profiles/r03_gemm_traffic.json"
             else:
-                traffic_note = "profiles/r02_gemm_traffic.json is stale (kernel sources changed since it was collected): ignored"
+                traffic_note = "profiles/r03_gemm_traffic.json is stale (kernel sources changed since it was collected): ignored"
         n_tok = (64 // 16) * (frames // 16) + 1
         exec_gf = executed_gflop_per_clip(model_type, mode, n_tok)
         hbm_kernels = {}
@@ -292,7 +295,7 @@ def main():
             "config": {"workload": args.workload, "encoder": model_type, "clip_seconds": seconds, "n_mels": 64,
                        "clips_per_gpu": B, "global_batch": B * world, "step": "logmel+augment+fwd+bwd+allreduce+adamw" +
                        ("+ema" if mode == "byol" else ""), "hip_graph": trainer._graph is not None,
-                       "eager_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
+                       "profiled_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
                        "loss": round(loss_val, 4)},
             "roofline": {"bound": "mfma", "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
                          "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -300,8 +303,8 @@ def main():
                          "algorithmic_flop_per_launch": round(d_fl / d_n), "algorithmic_bytes_per_launch": round(d_nb / d_n),
                          "launches": d_n, "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
                          "share_of_step": round((d_ms / psteps) / (dt / args.steps * 1e3), 4),
-                         "timing": f"HIP events on the launch stream around every sa_gemm_bf16 launch of {psteps} eager steps run right after the timed region "
-                                   f"(the timed region replays the step as a HIP graph: {'yes' if trainer._graph is not None else 'no'})",
+                         "timing": f"HIP events on the launch stream around every sa_gemm_bf16 launch of {psteps} steps of the same workload run right "
+                                   "after the timed region (the timed region itself carries no events: 2 x 160 of them per step cost 5 % of it)",
                          "all_gemm": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": len(prof),
                                       "share_of_step": round((gemm_ms / psteps) / (dt / args.steps * 1e3), 4),
                                       "by_kernel": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[3],

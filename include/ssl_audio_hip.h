@@ -74,6 +74,13 @@ int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
 /* Host policy knob (no reference counterpart): CUs the persistent GEMM grids may occupy, 0 = all.  Data-parallel runs reserve
  * the CUs RCCL's collective kernels hold during an all-reduce, so an overlapped GEMM does not spill into a second wave. */
 int sa_set_cu_budget(int32_t cus);
+/* Host policy knob (no reference counterpart; DDP / NCCL hide the problem it solves): dynamic tile hand-out in the persistent GEMM
+ * kernels.  on != 0: a workgroup starts on tile blockIdx and draws every later tile from a per-launch ticket counter (one memset node
+ * + the kernel, still capturable), so a workgroup that got its CU late -- RCCL's all-reduce kernels hold CUs while they run -- simply
+ * draws fewer tiles instead of finishing a whole static share late.  Results do not depend on the order tiles are drawn in.
+ * Costs 1.5-2 % of a launch on an undisturbed chip (one returning atomic per tile on the critical wave), so the default is off
+ * (SA_GEMM_DYNAMIC=1 in the environment turns it on) and the data-parallel trainer switches it on when collectives are active. */
+int sa_set_dynamic_tiles(int32_t on);
 
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
 int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

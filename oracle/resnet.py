@@ -52,16 +52,17 @@ def basic_block(x, p, pre, stride, bn_stats=None):
     return F.relu(out + identity)
 
 
-def forward(x, p, variant="resnet18", bn_stats=None, training=True):
-    """ResNet._forward_impl (models/resnet.py:255-274) with fc = Identity.  x [B, 1, F, T] -> [B, embed_dim]."""
+def forward(x, p, variant="resnet18", bn_stats=None, training=True, layers=None):
+    """ResNet._forward_impl (models/resnet.py:255-274) with fc = Identity.  x [B, 1, F, T] -> [B, embed_dim].  `layers`: blocks per stage
+    (default the ResNet-18 [2, 2, 2, 2]; [0, 0, 0, 0] = stem + max-pool + head only, for tests that isolate the stem)."""
     _TRAINING[0] = training
     try:
-        return _forward(x, p, variant, bn_stats)
+        return _forward(x, p, variant, bn_stats, layers or LAYERS)
     finally:
         _TRAINING[0] = True
 
 
-def _forward(x, p, variant, bn_stats):
+def _forward(x, p, variant, bn_stats, layers):
     cfg = VARIANTS[variant]
     s = cfg["strides"]
     h = x
@@ -69,7 +70,7 @@ def _forward(x, p, variant, bn_stats):
         h = F.relu(_bn(_conv(h, p, f"conv1.{3 * l}", st, 1), p, f"conv1.{3 * l + 1}", bn_stats))
     h = F.max_pool2d(R.qf(h), kernel_size=3, stride=2, padding=1)
     for li in range(4):
-        for b in range(LAYERS[li]):
+        for b in range(layers[li]):
             h = basic_block(h, p, f"layer{li + 1}.{b}.", s[li + 1] if b == 0 else 1, bn_stats)
     if cfg["regp"]:
         h = h.permute(0, 3, 2, 1)                                          # (batch, time, mel, ch)

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],
     "sa_layernorm_bwd_workspace_bytes": [I32, I32],
     "sa_set_cu_budget": [I32],
+    "sa_set_dynamic_tiles": [I32],
     "sa_lars_step": [P, P, P, I64, F32, F32, F32, F32, I32, P, P, P],
     "sa_gemm_colsum_workspace_bytes": [I32, I32],
     "sa_gemm_splitk_workspace_bytes": [I32, I32, I32],

@@ -81,7 +81,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t ld, int B, 
     const int b = (int)(i / C), c = (int)(i % C);
     float v = (x[(int64_t)b * ld + c] - mean[c]) * rstd[c];
     if (gamma) v = v * gamma[c] + beta[c];
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu) v = relu_f(v);
     if (y_f32) y_f32[(int64_t)b * ldy + c] = v;
     if (y_bf16) y_bf16[(int64_t)b * ldy + c] = f2bf(v);
   }

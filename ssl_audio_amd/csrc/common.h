@@ -39,6 +39,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ReLU that keeps a NaN a NaN, as torch's relu does (fmaxf / v_max_f32 return the non-NaN operand, which would turn a diverged
+// activation into a clean-looking zero and hide the non-finite loss the step's device-side gate and the host check look for)
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void relu_mask_fwd_kernel(const float* __restr
     const int cc = (int)(i % c4);
     const int64_t m = i / c4;
     const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + cc * 4);
-    float o[4] = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+    float o[4] = {relu_f(v.x), relu_f(v.y), relu_f(v.z), relu_f(v.w)};
     if (keep) {
       const uint32_t k4 = *reinterpret_cast<const uint32_t*>(keep + m * C + cc * 4);
 #pragma unroll

@@ -13,6 +13,35 @@
 
 int sagemm::g_cu_budget = 0;
 
+// ---- dynamic tile hand-out ---------------------------------------------------------------------------------------------------------
+// Under data parallelism RCCL's kernels hold some CUs for the length of an all-reduce.  A persistent grid with STATIC striding then
+// finishes late by a whole share of tiles on every workgroup that had to wait for a CU; with tickets drawn from one counter a late
+// workgroup just draws fewer tiles.  One word per launch out of a ring (launches on one stream are ordered; 256 launches later a slot
+// is long dead), zeroed by a memset node ahead of the kernel so the entry point stays capturable and stateless.
+namespace {
+__device__ int g_tile_tickets[256];
+int g_dynamic_tiles = -1;                 // -1: not decided yet (SA_GEMM_DYNAMIC; default off: measured 1.5-2 % on an undisturbed chip)
+}  // namespace
+
+int* sagemm::next_tile_counter(hipStream_t stream) {
+  if (g_dynamic_tiles < 0) {
+    const char* e = getenv("SA_GEMM_DYNAMIC");
+    g_dynamic_tiles = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (!g_dynamic_tiles) return nullptr;
+  static int* base = nullptr;
+  static unsigned turn = 0;
+  if (!base && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_tile_tickets)) != hipSuccess) return nullptr;
+  int* slot = base + (turn++ & 255u);
+  if (hipMemsetAsync(slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+  return slot;
+}
+
+extern "C" int sa_set_dynamic_tiles(int32_t on) {
+  g_dynamic_tiles = on ? 1 : 0;
+  return 0;
+}
+
 namespace {
 
 template <bool A_KM, bool B_KM, bool SWAP>
@@ -377,13 +406,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   coords(t, m0, n0);
   stage_all(smem, m0, n0, 0);
   int cur = 0;
+  // dynamic hand-out (p.tile_counter; the host sets it only when ksteps >= 2): lane 0 of wave 0 draws the NEXT tile's ticket at the
+  // top of a tile, the value crosses to the other waves through one LDS word behind the first K-step's barrier, and is first needed
+  // in the last K-step (prefetch of the next tile's first K-tile)
+  const bool dyn = p.tile_counter != nullptr;
+  int* const ticket_word = reinterpret_cast<int*>(smem + 2 * BUF);
   while (true) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int tnext = t + nwg;
-    const bool has_next = tnext < ntiles;
+    int tnext = t + nwg;
+    int ticket = 0;
+    if (dyn && threadIdx.x == 0) ticket = atomicAdd(p.tile_counter, 1);
+    bool has_next = tnext < ntiles;
     int m0n = 0, n0n = 0;
-    if (has_next) coords(tnext, m0n, n0n);
+    if (!dyn && has_next) coords(tnext, m0n, n0n);
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -450,7 +486,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
           for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j][ks], fa[i][ks], acc[4 + i][j], 0, 0, 0);
       if (more) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dyn && kt == 0) {
+          if (threadIdx.x == 0) *ticket_word = nwg + ticket;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
+        if (dyn && kt == 0) {
+          tnext = __builtin_amdgcn_readfirstlane(*ticket_word);
+          has_next = tnext < ntiles;
+          if (has_next) coords(tnext, m0n, n0n);
+        }
         cur ^= 1;
       }
     }
@@ -486,6 +531,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
   }
 }
 
+constexpr int PERSIST_LDS = 8 * TILE_BYTES + 16;     // two 64 KiB stages + the ticket word of the dynamic tile hand-out
+
 template <bool A_KM, bool B_KM>
 int launch256_persist(GemmParams p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
@@ -500,27 +547,28 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
     }
     slots = prop.multiProcessorCount;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<A_KM, B_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              8 * TILE_BYTES);
+                              PERSIST_LDS);
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   const dim3 grid(ntiles < budget_slots(slots) ? ntiles : budget_slots(slots));
+  p.tile_counter = ((p.K + BK - 1) / BK >= 2 && ntiles > (int)grid.x) ? sagemm::next_tile_counter(stream) : nullptr;
   if constexpr (A_KM && B_KM) {            // the forward layout gets kernels specialised on the compact epilogues 1..3
 #define SA_EPI_CASE(E)                                                                                                     \
   case E: {                                                                                                                \
     static bool cfg = false;                                                                                               \
     if (!cfg) {                                                                                                            \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_persist_kernel<true, true, E>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);                                  \
       cfg = true;                                                                                                          \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, E>), grid, dim3(512), 8 * TILE_BYTES, stream, p);             \
+    hipLaunchKernelGGL((gemm256_persist_kernel<true, true, E>), grid, dim3(512), PERSIST_LDS, stream, p);                \
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
     return 0;                                                                                                              \
   }
     switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(5) SA_EPI_CASE(6) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
 #undef SA_EPI_CASE
   }
-  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), 8 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), PERSIST_LDS, stream, p);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent)");
   return 0;
 }
@@ -1031,6 +1079,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.row_group = a->row_group; p.split_k = a->split_k; p.accumulate = a->accumulate;
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
   p.split_ws = a->split_k > 1 ? a->splitk_ws : nullptr;
+  p.tile_counter = nullptr;
   static const char* es_env = getenv("SA_GEMM_EPI_COMPACT");
   p.epi_kind = 0;
   {

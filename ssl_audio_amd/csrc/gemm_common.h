@@ -39,7 +39,12 @@ struct GemmParams {
   int epi_kind;      // 1..4: one of the compact epilogues applies (wave_epilogue_compact); 0: general epilogue
   int nt_store;      // bf16 outputs with non-temporal stores
   float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
+  int* tile_counter; // dynamic tile hand-out of the persistent kernels: a zeroed device word; workgroup b starts on tile b and draws every
+                     // later tile as gridDim.x + atomicAdd(tile_counter, 1).  null: static striding (tile b, b + grid, ...)
 };
+
+// A zeroed ticket word for one launch (hipMemsetAsync on `stream`, capturable), or null when dynamic hand-out is off.
+int* next_tile_counter(hipStream_t stream);
 
 
 // gemm_phase.hip: launches the phased kernel for (layout, split) if it covers the problem (compact epilogue kinds 1/3/5/6 or split-K

@@ -142,10 +142,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
   // ---- stream cursor: position of K-tile s + 2 (c2) and s + 1 (c1) while K-tile s is consumed
   struct Pos { int m0, n0, k0, valid; };
   int cu = u, cm0 = m0, cn0 = n0, ck = kt0, ckend = kt0 + nk;
+  // dynamic hand-out (p.tile_counter, set by the host only when every unit has >= 6 K-tiles): thread 0 draws the ticket of the NEXT
+  // unit during the first K-tile of a unit, publishes it through the first word of wave 0's (idle) epilogue scratch during the second
+  // and every wave has it in an SGPR before the cursor -- three K-tiles ahead of the compute -- crosses into that unit
+  const bool dyn = p.tile_counter != nullptr;
+  int* const ticket_word = reinterpret_cast<int*>(smem + 2 * PH_BUF);
+  int unext = 0x7fffffff;                                    // dynamic mode: the drawn id of the next unit (until drawn: none)
   auto take = [&]() {                                        // current cursor position, then advance by one K-tile
     Pos q{cm0, cn0, ck * BK, cu < nunits};
     if (q.valid && ++ck == ckend) {
-      cu += nwg;
+      cu = dyn ? unext : cu + nwg;
       if (cu < nunits) {
         int nk2;
         unit(cu, cm0, cn0, ck, nk2);
@@ -216,10 +222,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    int ticket = 0;
     for (int kt = 0; kt < nk; ++kt, ++sidx) {
       const int buf = sidx & 1;
       const char* cur = smem + buf * PH_BUF;
       bool fresh = EPI_STORES > 0 && after_full && kt <= 1;
+      if (dyn && kt == 0 && threadIdx.x == 0) ticket = atomicAdd(p.tile_counter, 1);
+      if (dyn && kt == 1 && threadIdx.x == 0) *ticket_word = nwg + ticket;
       // ---- P1: quadrant (A_lo, B_lo)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
       SA_L_END()
       SA_QUAD(4, 0, fb0)
       SA_M_END()
+      if (dyn && kt == 1) unext = __builtin_amdgcn_readfirstlane(*ticket_word);     // (six barriers after thread 0's write)
       c1 = c2;
       c2 = take();
     }
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_phase_kernel(const GemmParams 
     }
     PH_T(6)
     after_full = m0 + 256 <= p.M && n0 + 256 <= p.N;
-    u += nwg;
+    u = dyn ? unext : u + nwg;
     if (u >= nunits) break;
     unit(u, m0, n0, kt0, nk);
   }
@@ -334,7 +344,11 @@ int launch256_phase_one(const GemmParams& p, hipStream_t stream, int slots) {
   }
   const int nunits = p.tiles_m * p.tiles_n * p.split_k;
   const dim3 grid(nunits < budget_slots(slots) ? nunits : budget_slots(slots));
-  hipLaunchKernelGGL((gemm256_phase_kernel<A_KM, B_KM, SPLIT, EPI>), grid, dim3(512), PH_LDS, stream, p);
+  GemmParams q = p;
+  const int ksteps_all = (p.K + BK - 1) / BK;
+  const int min_nk = SPLIT ? ksteps_all / p.split_k : ksteps_all;                 // (the shortest K slice)
+  q.tile_counter = (min_nk >= 6 && nunits > (int)grid.x) ? sagemm::next_tile_counter(stream) : nullptr;
+  hipLaunchKernelGGL((gemm256_phase_kernel<A_KM, B_KM, SPLIT, EPI>), grid, dim3(512), PH_LDS, stream, q);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 phased)");
   return 0;
 }

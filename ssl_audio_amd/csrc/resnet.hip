@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restri
                                                            bf16_t* __restrict__ y16) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 a = reinterpret_cast<const float4*>(z)[i], b = reinterpret_cast<const float4*>(idn)[i];
-    const float4 r = make_float4(fmaxf(a.x + b.x, 0.f), fmaxf(a.y + b.y, 0.f), fmaxf(a.z + b.z, 0.f), fmaxf(a.w + b.w, 0.f));
+    const float4 r = make_float4(relu_f(a.x + b.x), relu_f(a.y + b.y), relu_f(a.z + b.z), relu_f(a.w + b.w));
     reinterpret_cast<float4*>(y32)[i] = r;
     if (y16) reinterpret_cast<bf16x4*>(y16)[i] = bf16x4{f2bf(r.x), f2bf(r.y), f2bf(r.z), f2bf(r.w)};
   }

@@ -54,13 +54,19 @@ def init_from_env(backend=None):
 # last workgroups late (estimated: one ~290 us launch per gradient bucket delayed by up to the ~250 us all-reduce, ~6 % of a
 # step).  SA_RCCL_CUS=n reserves n CUs instead (RCCL bounded to n channels, persistent grids and the split-K heuristic sized
 # to the rest): measured cost 7.5 % of a step through tile-round quantisation (3012 tiles: 12 rounds on 256 CUs, 13 on 240),
-# i.e. no better, so the default is 0 (off).  The real fix is dynamic tile hand-out in the persistent kernels (next round).
+# i.e. no better, so the default is 0 (off).  The fix built in round 3 is dynamic tile hand-out in the persistent kernels
+# (sa_set_dynamic_tiles, switched on below whenever collectives are active).
 RCCL_CUS = int(os.environ.get("SA_RCCL_CUS", "0"))
 
 
 def reserve_cus_for_collectives():
-    """Called by the trainer once the process group exists (no-op unless SA_RCCL_CUS > 0 and collectives are active)."""
+    """Called by the trainer (and by GradSumParallel) once the process group exists.  With collectives active the persistent GEMM
+    kernels hand their tiles out dynamically (sa_set_dynamic_tiles): a workgroup whose CU was held by an RCCL kernel then draws fewer
+    tiles instead of finishing a static share late.  SA_RCCL_CUS > 0 additionally reserves CUs (the static alternative, off by
+    default)."""
     from . import ops
+    if collectives_active() and torch.cuda.is_available() and os.environ.get("SA_GEMM_DYNAMIC", "1") != "0":
+        ops.set_dynamic_tiles(True)
     if RCCL_CUS > 0 and collectives_active() and torch.cuda.is_available() and dist.get_backend() == "nccl":
         _, cus = ops.device_info()
         ops.set_cu_budget(max(cus - RCCL_CUS, cus // 2))
@@ -131,6 +137,7 @@ class GradSumParallel(nn.Module):
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self._flat = [None] * len(self._buckets)    # allocated on the first backward (the parameters' device is final by then)
         self._reset()
+        reserve_cus_for_collectives()
 
     def _reset(self):
         self._arrived = [0] * len(self._buckets)

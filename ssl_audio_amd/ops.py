@@ -142,6 +142,11 @@ def set_cu_budget(cus):
     CU_BUDGET = int(cus) if cus else None
 
 
+def set_dynamic_tiles(on):
+    """Dynamic tile hand-out in the persistent GEMM kernels (include/ssl_audio_hip.h: sa_set_dynamic_tiles)."""
+    check(lib().sa_set_dynamic_tiles(int(bool(on))), "sa_set_dynamic_tiles")
+
+
 def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False, epi1=False):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
     override); used to label bench.py's per-launch timings with the names rocprofv3 reports.  epi3: the launch has the compact

@@ -92,6 +92,46 @@ def main():
     refw = dY.double().T @ X.double()
     ew = float((out.cpu().double() - refw).norm() / refw.norm())
     assert ew < 1e-5, ew
+    # dynamic tile hand-out (sa_set_dynamic_tiles): more tiles than CUs and >= 6 K-tiles per tile, so that the persistent AND the phased
+    # kernel draw tickets; every epilogue family; bit-identical to static striding (the order tiles are drawn in cannot matter) and
+    # right against fp64.  Ragged M: the last row panel is partly outside.
+    Md, Nd, Kd = 8300, 2304, 768                        # 33 x 9 = 297 tiles of 256 x 256, 12 K-tiles each
+    Ad = bf(torch.randn(Md, Kd, generator=g)); Bd_ = bf(torch.randn(Nd, Kd, generator=g) * 0.05)
+    biasd = torch.randn(Nd, generator=g).to(dev); resd = torch.randn(Md, Nd, generator=g).to(dev)
+    auxd = bf(torch.randn(Md, Nd, generator=g)).to(dev)
+    accd = Ad.double() @ Bd_.double().T
+    Ag, Bg = Ad.to(dev), Bd_.to(dev)
+    runs = {}
+    for dyn in (False, True):
+        ops.set_dynamic_tiles(dyn)
+        o1 = torch.empty(Md, Nd, device=dev, dtype=torch.bfloat16)
+        ops.gemm(Ag, Bg, bias=biasd, out_bf16=o1)                                                   # kind 1
+        o3 = torch.empty(Md, Nd, device=dev)
+        ops.gemm(Ag, Bg, bias=biasd, residual=resd, out_f32=o3)                                     # kind 3 (phased)
+        o6, a6 = torch.empty(Md, Nd, device=dev, dtype=torch.bfloat16), torch.empty(Md, Nd, device=dev, dtype=torch.bfloat16)
+        ops.gemm(Ag, Bg, bias=biasd, act=3, aux_out=a6, out_bf16=o6)                                # kind 6
+        o5 = torch.empty(Md, Nd, device=dev, dtype=torch.bfloat16); cs5 = torch.zeros(Nd, device=dev)
+        ops.gemm(Ag, Bg, act=4, aux_in=auxd, out_bf16=o5, colsum_out=cs5)                           # kind 5 + fused column sums
+        Bl = bf(torch.randn(Nd // 3, 4 * Kd, generator=torch.Generator().manual_seed(9)) * 0.03).to(dev)
+        Al = bf(torch.randn(Md, 4 * Kd, generator=torch.Generator().manual_seed(10))).to(dev)
+        ol = torch.empty(Md, Nd // 3, device=dev, dtype=torch.bfloat16)
+        ops.gemm(Al, Bl, out_bf16=ol)                                                               # kind 1, K = 3072 (phased), 99 tiles: static
+        torch.cuda.synchronize()
+        runs[dyn] = (o1, o3, o6, a6, o5, cs5, ol)
+    ops.set_dynamic_tiles(True)
+    for x, y in zip(runs[False][:5], runs[True][:5]):
+        assert torch.equal(x, y), "dynamic tile hand-out changed a result"
+    assert torch.equal(runs[False][6], runs[True][6])
+    assert float((runs[True][5] - runs[False][5]).abs().max()) <= 1e-3 * float(runs[False][5].abs().max())      # (column partials meet in fixed slots: equal up to nothing)
+    r1 = accd + biasd.cpu().double()
+    assert float((runs[True][0].cpu().double() - r1).norm() / r1.norm()) < 4e-3
+    r3 = r1 + resd.cpu().double()
+    assert float((runs[True][1].cpu().double() - r3).norm() / r3.norm()) < 1e-5
+    g6 = torch.nn.functional.gelu(r1)
+    assert float((runs[True][2].cpu().double() - g6).norm() / g6.norm()) < 4e-3
+    r5 = accd * auxd.cpu().double()
+    assert float((runs[True][4].cpu().double() - r5).norm() / r5.norm()) < 4e-3
+    assert float((runs[True][5].cpu().double() - r5.sum(0)).norm() / r5.sum(0).norm()) < 1e-4
     torch.cuda.synchronize()
     print(f"ok tile={os.environ.get('SA_GEMM_TILE', 'default')} ring_wgrad={os.environ.get('SA_GEMM_WGRAD_RING', '0')} worst={worst:.2e} wgrad={ew:.2e}")
 

@@ -218,7 +218,7 @@ def test_custom_ops_cover_every_compute_entry_point():
     from ssl_audio_amd import _lib, custom_ops, ops
     covered = {sym for sym, _ in custom_ops.SCHEMAS.values()}
     plain = {s for s in _lib.header_symbols() if s not in covered}
-    assert plain == {"sa_abi_version", "sa_last_error", "sa_device_info", "sa_set_cu_budget", "sa_bn_tall_workspace_bytes",
+    assert plain == {"sa_abi_version", "sa_last_error", "sa_device_info", "sa_set_cu_budget", "sa_set_dynamic_tiles", "sa_bn_tall_workspace_bytes",
                      "sa_gemm_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes"}, plain
     assert covered <= set(_lib.header_symbols())
     for name, (sym, schema) in custom_ops.SCHEMAS.items():
