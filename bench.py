@@ -262,15 +262,15 @@ def main():
         d_tflops = d_fl / (d_ms * 1e-3) / 1e12
         traffic, traffic_note = None, "no PMC summary for this workload"
         tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "vit_base_bt_10s" and B == 128:
-            # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/collect_traffic.sh), valid
-            # only for the kernel sources it was collected with
+        if os.path.exists(tpath) and B == bpg:
+            # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/profile_round.sh), per
+            # workload, valid only for the kernel sources it was collected with
             tj = json.load(open(tpath))
-            if tj.get("source_sha") == source_sha():
-                traffic = tj.get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE) of this command, profiles/r03_gemm_traffic.json"
-            else:
+            if tj.get("source_sha") != source_sha():
                 traffic_note = "profiles/r03_gemm_traffic.json is stale (kernel sources changed since it was collected): ignored"
+            elif args.workload in tj.get("workloads", {}):
+                traffic = tj["workloads"][args.workload].get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of this command, profiles/r03_gemm_traffic.json"
         n_tok = (64 // 16) * (frames // 16) + 1
         exec_gf = executed_gflop_per_clip(model_type, mode, n_tok)
         hbm_kernels = {}

@@ -1,12 +1,14 @@
 """GEMM micro-benchmark at the ViT-B step's shapes AND epilogues (M = 256 sequences x 249 tokens): the 12 launches one transformer
 block's forward + backward makes, exactly as engine.block_forward / block_backward call them.  Random operands (rule 25).
-   python scripts/bench_gemm.py [filter] [reps]          (SA_GEMM_TILE / SA_GEMM_WGRAD_PHASE select kernels, read once per process)"""
+   python scripts/bench_gemm.py [filter] [reps]          (SA_GEMM_TILE / SA_GEMM_WGRAD_PHASE select kernels, read once per process)
+   SA_BENCH_D / SA_BENCH_SEQS: model width and sequences per step (default 768 / 256 = ViT-B at 128 clips; 192 / 512 = ViT-T at 256)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl_audio_amd import ops
 dev = torch.device("cuda:0")
-M, d = 63744, 768
+d = int(os.environ.get("SA_BENCH_D", "768"))
+M = int(os.environ.get("SA_BENCH_SEQS", "256")) * 249
 g = torch.Generator(device=dev).manual_seed(0)
 def rb(*s): return torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 def rf(*s): return torch.randn(*s, device=dev, generator=g)

@@ -39,6 +39,18 @@ res["per_kernel"] = {k: summarise(v) for k, v in tot.items() if k != "__all__"}
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench
 res["source_sha"] = bench.source_sha()          # bench.py ignores this file once the kernel sources differ
-res["note"] = "sa_gemm_bf16 launches of `bench.py --steps 2 --warmup 1` (3 steps); FETCH_SIZE doubled per the gfx950 correction"
-json.dump(res, open(out, "w"), indent=1)
+res["note"] = "sa_gemm_bf16 launches of `bench.py --steps 2 --warmup 1 --profile_steps 1` (5 steps); FETCH_SIZE doubled per the gfx950 correction"
+workload = sys.argv[3] if len(sys.argv) > 3 else "vit_base_bt_10s"
+# one file for all workloads: {"source_sha": ..., "workloads": {name: summary}}; an entry collected at other kernel sources is dropped
+import os
+allw = {}
+if os.path.exists(out):
+    try:
+        old = json.load(open(out))
+        if old.get("source_sha") == res["source_sha"]:
+            allw = old.get("workloads", {})
+    except Exception:
+        allw = {}
+allw[workload] = {k: v for k, v in res.items() if k not in ("source_sha",)}
+json.dump({"source_sha": res["source_sha"], "workloads": allw}, open(out, "w"), indent=1)
 print(json.dumps({k: (v if k != "per_kernel" else {n: round(x["hbm_bytes_per_launch"] / 1e6, 1) for n, x in v.items()}) for k, v in res.items()}))
