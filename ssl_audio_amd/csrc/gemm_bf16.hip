@@ -1112,7 +1112,10 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
 
   // large dense problems go to the 256 x 256 kernel (half the operand bytes per FLOP through the CU's L2 path)
   static const char* force = getenv("SA_GEMM_TILE");
-  const bool big = a->split_k == 1 && a->M >= 1024 && a->N >= 256 && (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 128;
+  static const char* bign_env = getenv("SA_GEMM_BIG_N");       // experiment knob: narrowest output that still takes the 256 x 256 kernels
+  const int big_n = bign_env ? atoi(bign_env) : 192;           // d = 192 (ViT-T) outputs: 25 % of a 256-wide tile is padding, still 10-30 % faster
+                                                               // than the 128^2 kernel with its general epilogue (scripts/bench_gemm.py, SA_BENCH_D=192)
+  const bool big = a->split_k == 1 && a->M >= 1024 && a->N >= big_n && (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 128;
   // Measured on the ViT-B shapes (scripts/bench_gemm.py, random operands): the 128^2 kernel (mode 1, two 4-wave
   // workgroups per CU) beats the 256x128 three-stage (mode 3) and 256^2 (mode 2) variants at K = 768;
   // those stay selectable through SA_GEMM_TILE for experiments and are parity-tested.
@@ -1125,7 +1128,9 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // ... and on the plain bias -> bf16 epilogue once the reduction is long (K >= 1536: 266 vs 285 us at K = 3072, 197 vs 211 at 2304; a tie at 768).
   static const char* k1_env = getenv("SA_GEMM_PHASE_K1");      // experiment knob: minimum K for mode A on epilogue kind 1 (0: never)
   const int k1_min = k1_env ? atoi(k1_env) : 1536;
-  const bool nt_phase = a->a_kmajor && a->b_kmajor && a->K >= 2 * BK && (p.epi_kind == 3 || (p.epi_kind == 1 && k1_min > 0 && a->K >= k1_min));
+  // ... and on narrow outputs (one column tile: N <= 256) from K = 512 on: ViT-T's fc1 / qkv data gradients 59 -> 51 us, 43 -> 41 us
+  const bool nt_phase = a->a_kmajor && a->b_kmajor && a->K >= 2 * BK &&
+                        (p.epi_kind == 3 || (p.epi_kind == 1 && k1_min > 0 && (a->K >= k1_min || (a->N <= 256 && a->K >= 512))));
   char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : (nt_phase ? 'A' : '6')) : '1');
   if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");

@@ -154,12 +154,12 @@ def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False
     (bias ->) bf16 epilogue, phased too once the reduction is long (K >= 1536: the fc1 / qkv data gradients)."""
     if split_k > 1:
         return "gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>"
-    big = M >= 1024 and N >= 256 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
+    big = M >= 1024 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
     if not big:
         return "gemm_kernel"
     if a_kmajor and not b_kmajor:
         return "gemm256_ring_kernel"
-    phased = a_kmajor and b_kmajor and K >= 128 and (epi3 or (epi1 and K >= 1536))
+    phased = a_kmajor and b_kmajor and K >= 128 and (epi3 or (epi1 and (K >= 1536 or (N <= 256 and K >= 512))))
     return "gemm256_phase_kernel" if phased else "gemm256_persist_kernel"
 
 
