@@ -59,52 +59,63 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   const int xhi = min(cw - 1, (int)floorf(__fmul_rn(sx, (float)(t0 + nt - 1))) + 2);
   const int wt = xhi - xlo + 1;  // host guarantees wt <= LDS_W via TT
 
-  // ---- stage 1: mixed source tile [ch x wt]
-  for (int idx = threadIdx.x; idx < ch * wt; idx += 256) {
-    const int yy = idx / wt, xx = idx - yy * wt;
-    const int r = ci + yy - py, cc = cj + xlo + xx - px;  // input coordinates
-    float v = 0.f;
-    if (r >= 0 && r < F_in && cc >= 0 && cc < T_in) {
-      v = x[(int64_t)r * T_in + cc];
-      if (z) v = logf(wa * expf(v) + wb * expf(z[(int64_t)r * T_in + cc]) + kEps32);
+  // ---- stage 1: mixed source tile [ch x wt].  Thread -> (row pair, column): no per-element division, a wave reads 64 consecutive
+  // source columns of one row (256 contiguous bytes of x and of the bank entry z)
+  for (int yy = threadIdx.x >> 7; yy < ch; yy += 2) {
+    const int r = ci + yy - py;
+    const bool row_in = r >= 0 && r < F_in;
+    for (int xx = threadIdx.x & 127; xx < wt; xx += 128) {
+      const int cc = cj + xlo + xx - px;  // input coordinates
+      float v = 0.f;
+      if (row_in && cc >= 0 && cc < T_in) {
+        v = x[(int64_t)r * T_in + cc];
+        if (z) v = logf(wa * expf(v) + wb * expf(z[(int64_t)r * T_in + cc]) + kEps32);
+      }
+      tile[yy * LDS_W + xx] = v;
     }
-    tile[yy * LDS_W + xx] = v;
   }
   __syncthreads();
 
-  // ---- stage 2: bicubic + fade
+  // ---- stage 2: bicubic + fade.  Thread -> output column tx (fixed) x rows fy = rg, rg + 4, ...: the horizontal taps and weights are
+  // computed once per thread, the vertical ones are wave-uniform, a wave stores 64 consecutive frames of one mel row (256 bytes)
   const float fade_step = T_out > 1 ? (pr.tail - pr.head) / (float)(T_out - 1) : 0.f;
   float* o = out + (int64_t)view * F_out * T_out;
-  for (int idx = threadIdx.x; idx < F_out * nt; idx += 256) {
-    const int fy = idx / nt, tx = idx - fy * nt;
+  const int tx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  if (tx < nt) {
     const int t = t0 + tx;
     // rounded products (no FMA contraction into the fraction): PyTorch's CPU kernel rounds scale*index to fp32 first
-    float rx = sx * (float)t, ry = sy * (float)fy;
-    asm volatile("" : "+v"(rx), "+v"(ry));   // keep the ROUNDED products: hipcc would otherwise contract x*y - floor into an fma
-    const float fx = floorf(rx), fyf = floorf(ry);
-    float wx[4], wy[4];
+    float rx = sx * (float)t;
+    asm volatile("" : "+v"(rx));             // keep the ROUNDED product: hipcc would otherwise contract x*y - floor into an fma
+    const float fx = floorf(rx);
+    float wx[4];
     cubic_w(rx - fx, wx);
-    cubic_w(ry - fyf, wy);
-    const int ix = (int)fx, iy = (int)fyf;
-    int cx[4], cy[4];
+    const int ix = (int)fx;
+    int cx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      cx[k] = min(max(ix - 1 + k, 0), cw - 1) - xlo;  // taps clamp to the CROP bounds (PyTorch border rule)
-      cy[k] = min(max(iy - 1 + k, 0), ch - 1);
-    }
-    float acc = 0.f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float* row = tile + cy[a] * LDS_W;
-      const float r = row[cx[0]] * wx[0] + row[cx[1]] * wx[1] + row[cx[2]] * wx[2] + row[cx[3]] * wx[3];
-      acc += r * wy[a];
-    }
+    for (int k = 0; k < 4; ++k) cx[k] = min(max(ix - 1 + k, 0), cw - 1) - xlo;  // taps clamp to the CROP bounds (PyTorch border rule)
+    float fade = 0.f;
     if (do_fade) {
       // torch.linspace: first half counts up from head, second half counts down from tail
       const int half = T_out / 2;
-      acc += (t < half) ? pr.head + fade_step * (float)t : pr.tail - fade_step * (float)(T_out - 1 - t);
+      fade = (t < half) ? pr.head + fade_step * (float)t : pr.tail - fade_step * (float)(T_out - 1 - t);
     }
-    o[(int64_t)fy * T_out + t] = acc;
+    for (int fy = rg; fy < F_out; fy += 4) {
+      float ry = sy * (float)fy;
+      asm volatile("" : "+v"(ry));
+      const float fyf = floorf(ry);
+      float wy[4];
+      cubic_w(ry - fyf, wy);
+      const int iy = (int)fyf;
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float* row = tile + min(max(iy - 1 + a, 0), ch - 1) * LDS_W;
+        const float r = row[cx[0]] * wx[0] + row[cx[1]] * wx[1] + row[cx[2]] * wx[2] + row[cx[3]] * wx[3];
+        acc += r * wy[a];
+      }
+      if (do_fade) acc += fade;
+      o[(int64_t)fy * T_out + t] = acc;
+    }
   }
 }
 

@@ -68,6 +68,13 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
   float* xr = ex_re[w];
   float* xi = ex_im[w];
   const int lo = mel_lo[lane], len = mel_len[lane];
+  // longest band of the table (wave-uniform): the filter loop below runs this many iterations on every lane -- the weight table is
+  // zero-padded to it -- so that it has a uniform trip count and its loads pipeline (a per-lane `len` bound made every iteration a
+  // dependent global load -> LDS read -> fma round trip: ~8 k cycles of latency per frame)
+  int maxlen = len;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
 
   for (int f = 0; f < FR_PER_WAVE; ++f) {
     const int to = tb + w * FR_PER_WAVE + f;   // output frame index
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
       __builtin_amdgcn_wave_barrier();
       // ---- mel band `lane`: sum over its bin range
       float m = 0.f;
-      for (int q = 0; q < len; ++q) m += melw[q * NMEL + lane] * P[lo + q];
+#pragma unroll 8
+      for (int q = 0; q < maxlen; ++q) m += melw[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];   // same order of additions as before
       result = (logf(m + 1.1920929e-07f) - mean) * inv_std;
       __builtin_amdgcn_wave_barrier();
     }
