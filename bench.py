@@ -35,11 +35,12 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md: 6.29 TB/s meas
 
 
 def source_sha():
-    """Hash of the kernel sources: profiles/r03_gemm_traffic.json carries the hash it was collected at and is ignored when stale."""
-    import glob, hashlib
+    """Hash of the GEMM kernel sources: profiles/r03_gemm_traffic.json (HBM bytes of the GEMM launches) carries the hash it was collected
+    at and is ignored when stale."""
+    import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ssl_audio_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
+    for f in ("gemm_bf16.hip", "gemm_phase.hip", "gemm_common.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "ssl_audio_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

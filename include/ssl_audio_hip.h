@@ -289,6 +289,15 @@ int sa_nhwc_to_frames(const void* x_bf16, int32_t B, int32_t H, int32_t W, int32
 int sa_frames_to_nhwc(const float* da, int64_t lda, const float* db, int64_t ldb, int32_t B, int32_t H, int32_t W, int32_t C, float* dx, void* stream);
 int sa_meanmax_time_fwd(const float* x, int32_t B, int32_t T, int32_t D, float* out, int32_t* arg, void* stream);
 int sa_meanmax_time_bwd(const float* dout, const int32_t* arg, int32_t B, int32_t T, int32_t D, float* dx, void* stream);
+/* Squeeze-and-excitation gate of AudioNTT2022 (`squeeze_excitation=True`: SE_Block, model.py:196-213, placed after every MaxPool2d,
+ * model.py:141-142,150-151) on a channel-last bf16 map x [B][L = H*W][C]:  s = mean_l x;  e = sigmoid(W2 relu(W1 s))  (W1 [R][C], W2 [C][R],
+ * no biases, R = C / 16);  y = x * e.  fwd writes s [B][C], h [B][R] (the pre-ReLU hidden vector) and e [B][C] for the backward and y (bf16).
+ * bwd: dy fp32 [B][L][C] at the gate's output -> dx fp32 (through the scale and through the squeeze), dW1 / dW2 ACCUMULATED (atomics);
+ * scratch: 2 * B * C floats.  C must divide 256 (8..256), R <= 32. */
+int sa_se_fwd(const void* x_bf16, int32_t B, int32_t L, int32_t C, const float* w1, const float* w2, int32_t R, float* s, float* h, float* e,
+              void* y_bf16, void* stream);
+int sa_se_bwd(const float* dy, const void* x_bf16, int32_t B, int32_t L, int32_t C, const float* w1, const float* w2, int32_t R, const float* s,
+              const float* h, const float* e, float* dx, float* dw1, float* dw2, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------ ResNet-18 encoders (models/resnet.py: `resnet18`, `resnet18_ReGP_NRF`;
  * BASELINE config 1), channel-last like the stems above.  The 3x3 convolutions are sa_im2col3x3_bf16 + sa_gemm_bf16, the 1x1

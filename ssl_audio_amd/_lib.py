@@ -81,6 +81,8 @@ _SIGNATURES = {
     "sa_frames_to_nhwc": [P, I64, P, I64, I32, I32, I32, I32, P, P],
     "sa_meanmax_time_fwd": [P, I32, I32, I32, P, P, P],
     "sa_meanmax_time_bwd": [P, P, I32, I32, I32, P, P],
+    "sa_se_fwd": [P, I32, I32, I32, P, P, I32, P, P, P, P, P],
+    "sa_se_bwd": [P, P, I32, I32, I32, P, P, I32, P, P, P, P, P, P, P, P],
     "sa_attention_fwd": [P, I64, I64, I32, I32, I32, I32, F32, P, I64, P, P],
     "sa_attention_bwd": [P, I64, I64, I32, I32, I32, I32, F32, P, P, I64, P, P, P],
     "sa_bn_colstats": [P, I64, I32, I32, P, P, P],

@@ -86,6 +86,9 @@ SCHEMAS = {
     "nhwc_to_frames": ("sa_nhwc_to_frames", "(Tensor x16, int B, int H, int W, int C, Tensor(a!)? frames_bf16=None, Tensor(b!)? frames_f32=None) -> ()"),
     "frames_to_nhwc": ("sa_frames_to_nhwc", "(Tensor? da, Tensor? db, int B, int H, int W, int C, Tensor(a!) dx) -> ()"),
     "meanmax_time_fwd": ("sa_meanmax_time_fwd", "(Tensor x, Tensor(a!) out, Tensor(b!) arg) -> ()"),
+    "se_fwd": ("sa_se_fwd", "(Tensor x16, int B, int L, int C, Tensor w1, Tensor w2, Tensor(a!) s, Tensor(b!) h, Tensor(c!) e, Tensor(d!) y16) -> ()"),
+    "se_bwd": ("sa_se_bwd", "(Tensor dy, Tensor x16, int B, int L, int C, Tensor w1, Tensor w2, Tensor s, Tensor h, Tensor e, Tensor(a!) dx, "
+               "Tensor(b!) dw1, Tensor(c!) dw2) -> ()"),
     "meanmax_time_bwd": ("sa_meanmax_time_bwd", "(Tensor dout, Tensor arg, Tensor(a!) dx) -> ()"),
     "maxpool3s2_fwd": ("sa_maxpool3s2_fwd", "(Tensor x16, int B, int H, int W, int C, Tensor(a!) y16, Tensor(b!)? y32, Tensor(c!) idx) -> ()"),
     "maxpool3s2_bwd": ("sa_maxpool3s2_bwd", "(Tensor dy, Tensor idx, int B, int H, int W, int C, Tensor(a!) dx) -> ()"),

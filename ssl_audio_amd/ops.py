@@ -543,6 +543,18 @@ def meanmax_time_bwd(dout, arg, dx):
     check(lib().sa_meanmax_time_bwd(_p(_req(dout, F32, "dout")), _p(arg), B, T_, D, _p(_req(dx, F32, "dx")), _stream()), "sa_meanmax_time_bwd")
 
 
+def se_fwd(x16, B, L, C, w1, w2, s, h, e, y16):
+    """Squeeze-and-excitation gate on a channel-last bf16 map [B * L, C] (include/ssl_audio_hip.h: sa_se_fwd)."""
+    check(lib().sa_se_fwd(_p(_req(x16, BF16, "x")), B, L, C, _p(_req(w1, F32, "w1")), _p(_req(w2, F32, "w2")), w1.shape[0], _p(_req(s, F32, "s")),
+                          _p(_req(h, F32, "h")), _p(_req(e, F32, "e")), _p(_req(y16, BF16, "y")), _stream()), "sa_se_fwd")
+
+
+def se_bwd(dy, x16, B, L, C, w1, w2, s, h, e, dx, dw1, dw2):
+    ws = _workspace(2 * B * C * 4, dy.device, "se_block")
+    check(lib().sa_se_bwd(_p(_req(dy, F32, "dy")), _p(_req(x16, BF16, "x")), B, L, C, _p(_req(w1, F32, "w1")), _p(_req(w2, F32, "w2")), w1.shape[0],
+                          _p(s), _p(h), _p(e), _p(_req(dx, F32, "dx")), _p(_req(dw1, F32, "dw1")), _p(_req(dw2, F32, "dw2")), _p(ws), _stream()), "sa_se_bwd")
+
+
 def device_info():
     name = C.create_string_buffer(128)
     cus = C.c_int32(0)

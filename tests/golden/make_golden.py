@@ -708,6 +708,35 @@ def gen_schedule():
     save("schedule", **out)
 
 
+def gen_audiontt_se():
+    """AudioNTT2022(squeeze_excitation=True) (model.py:141-151,196-213): SE gates after both MaxPools, train mode, Dropout mask recovered
+    as in gen_audiontt.  Small widths (d 1280, hidden 256); the gates' Linear weights scaled up so that the sigmoid is not flat."""
+    out = {}
+    torch.manual_seed(0)
+    m = ref_model.AudioNTT2022(n_mels=64, d=1280, mlp_hidden_d=256, squeeze_excitation=True)
+    with torch.no_grad():
+        for k in (4, 9):
+            m.features[k].excitation[0].weight.mul_(4.0)
+            m.features[k].excitation[2].weight.mul_(4.0)
+    m.train()
+    for k, v in m.state_dict().items():
+        out["sd." + k] = t2n(v)
+    rec = {}
+    hook = m.fc[2].register_forward_hook(lambda mod, inp, o: rec.update(inp=inp[0].detach().clone(), out=o.detach().clone()))
+    torch.manual_seed(6)
+    x = torch.randn(3, 1, 64, 40)
+    y = m(x)
+    hook.remove()
+    keep = ((rec["out"] != 0) | (rec["inp"] == 0)).float()
+    w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    m.zero_grad()
+    (y * w).sum().backward()
+    out.update(x=t2n(x), y=t2n(y), keep=t2n(keep))
+    for n, prm in m.named_parameters():
+        out["grad." + n] = t2n(prm.grad)
+    save("audiontt_se", **out)
+
+
 def gen_hear():
     """HEAR wrapper (hear/sample/vit.py:40-247, hear/utils.py) run as the reference runs it: `ViTModelWrapper` + `get_scene_embeddings` /
     `get_timestamp_embeddings` on two 1.3 s clips.  Two absent third-party names are stood in for: `easydict.EasyDict` (attribute dict)
@@ -773,6 +802,7 @@ if __name__ == "__main__":
     gen_audiontt() if "audiontt" in sys.argv[1:] else None
     gen_bn_eval() if "bn_eval" in sys.argv[1:] else None
     gen_schedule() if "schedule" in sys.argv[1:] else None
+    gen_audiontt_se() if "audiontt_se" in sys.argv[1:] else None
     if len(sys.argv) > 1:
         sys.exit(0)
     gen_bt_loss()

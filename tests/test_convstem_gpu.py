@@ -313,6 +313,65 @@ def test_audiontt_golden(dev, golden):
         assert torch.equal(m(x), m(x))
 
 
+def test_audiontt_squeeze_excitation_golden(dev, golden):
+    """AudioNTT2022(squeeze_excitation=True) (SE_Block after each MaxPool, model.py:141-151,196-213) with the reference's weights: the
+    gate kernels against torch first (fp32 statistics on a bf16 map), then output rel 1e-2 and gradients against the reference -- the
+    four gate matrices and everything from the second BatchNorm's affine on at 3e-2, the parameters behind a BatchNorm backward by the
+    sensitivity-relative rule against the oracle's bf16 mirror."""
+    from ssl_audio_amd.audiontt import AudioNTT2022
+    # ---- kernels
+    gen = torch.Generator().manual_seed(3)
+    B, L, C, R = 3, 37 * 5, 64, 4
+    xm = torch.randn(B, L, C, generator=gen).to(torch.bfloat16)
+    w1, w2 = torch.randn(R, C, generator=gen) * 0.5, torch.randn(C, R, generator=gen) * 0.5
+    xd = xm.double().requires_grad_(True); w1d = w1.double().requires_grad_(True); w2d = w2.double().requires_grad_(True)
+    sref = xd.mean(1)
+    eref = torch.sigmoid(F.relu(sref @ w1d.T) @ w2d.T)
+    yref = xd * eref[:, None, :]
+    s_, h_, e_ = torch.empty(B, C, device=dev), torch.empty(B, R, device=dev), torch.empty(B, C, device=dev)
+    y16 = torch.empty(B * L, C, dtype=torch.bfloat16, device=dev)
+    ops.se_fwd(xm.view(B * L, C).to(dev), B, L, C, w1.to(dev), w2.to(dev), s_, h_, e_, y16)
+    assert rel(e_, eref) < 1e-5 and rel(y16.view(B, L, C), yref) < 4e-3
+    dy = torch.randn(B, L, C, generator=gen)
+    (yref * dy.double()).sum().backward()
+    dx = torch.empty(B * L, C, device=dev); dw1 = torch.zeros(R, C, device=dev); dw2 = torch.zeros(C, R, device=dev)
+    ops.se_bwd(dy.view(B * L, C).to(dev), xm.view(B * L, C).to(dev), B, L, C, w1.to(dev), w2.to(dev), s_, h_, e_, dx, dw1, dw2)
+    assert rel(dx.view(B, L, C), xd.grad) < 1e-5 and rel(dw1, w1d.grad) < 1e-5 and rel(dw2, w2d.grad) < 1e-5
+    # ---- the network
+    g = golden("audiontt_se")
+    m = AudioNTT2022(n_mels=64, d=1280, mlp_hidden_d=256, squeeze_excitation=True).to(dev)
+    sd = {k[3:]: T(v, dev, torch.long if "num_batches" in k else torch.float32) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)                       # same keys as the reference: features.{4,9}.excitation.{0,2}.weight, conv 2 at features.5
+    m.train()
+    x = T(g["x"], dev)
+    keep = T(g["keep"], dev).reshape(-1, 256).to(torch.uint8).contiguous()
+    y = m(x, keep=keep)
+    assert y.shape == (3, 1280) and rel(y, g["y"]) < 1e-2, rel(y, g["y"])
+    w = torch.linspace(-1, 1, y.numel(), device=dev).reshape(y.shape)
+    (y * w).sum().backward()
+    errs = {n: rel(p.grad, g["grad." + n]) for n, p in m.named_parameters() if float(np.linalg.norm(g["grad." + n])) > 1e-2}
+    print("audiontt + SE gradient rel errors vs the reference:", {k: round(v, 4) for k, v in errs.items()})
+    tight = {k: v for k, v in errs.items() if k.startswith(("features.6", "features.9"))}            # second BatchNorm's affine, second gate
+    mlp = {k: v for k, v in errs.items() if k.startswith("fc.")}                                     # behind two bf16 roundings of the gated map
+    assert len(tight) == 4 and max(tight.values()) < 3e-2 and len(mlp) == 4 and max(mlp.values()) < 7e-2, errs
+    from gradcheck import check_step_gradients
+    from oracle import audiontt as oa, rounding as R_
+    cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    names = [n for n, _ in m.named_parameters()]
+
+    def oracle_grads(mirror):
+        leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in cpu.items()}
+        with R_.mirror_hip_bf16(mirror):
+            ref = oa.forward(x.cpu(), leaf, T(g["keep"]))
+            gs = torch.autograd.grad((ref * w.cpu()).sum(), [leaf[k] for k in names])
+        return {k: gr for k, gr in zip(names, gs) if float(np.linalg.norm(g["grad." + k])) > 1e-2}
+
+    check_step_gradients("audiontt + SE", {n: p.grad for n, p in m.named_parameters()}, oracle_grads(True), oracle_grads(False), 12)
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x))
+
+
 def test_audiontt_default_size_through_model_wrapper(dev):
     """`--model_type audiontt` (the reference's default) behind ModelWrapper + BarlowTwinsHead: d = 3072, forward + backward at B = 8."""
     from ssl_audio_amd import hyperparameters as hp, model, utils

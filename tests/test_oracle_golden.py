@@ -433,6 +433,25 @@ def test_resnet_oracle_matches_reference(golden, variant):
             assert np.allclose(0.9 + 0.1 * var.numpy() * cnt / (cnt - 1), g[f"{variant}.after.{name}.running_var"], rtol=1e-4, atol=1e-6), name
 
 
+def test_audiontt_se_oracle_golden(golden):
+    """oracle.audiontt with SE gates (model.py:141-151,196-213) against the reference's AudioNTT2022(squeeze_excitation=True): output and
+    every parameter gradient, fp32."""
+    from oracle import audiontt as oa
+    g = golden("audiontt_se")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    names = [k for k in sd if not ("running" in k or "num_batches" in k)]
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    y = oa.forward(torch.from_numpy(g["x"]), leaf, torch.from_numpy(g["keep"]))
+    assert float((y.detach() - torch.from_numpy(g["y"])).abs().max()) < 1e-5
+    w = torch.linspace(-1, 1, y.numel()).reshape(y.shape)
+    gs = dict(zip(names, torch.autograd.grad((y * w).sum(), [leaf[k] for k in names])))
+    assert "features.4.excitation.0.weight" in gs and "features.9.excitation.2.weight" in gs
+    for k in names:
+        ref = torch.from_numpy(g["grad." + k])
+        if float(ref.norm()) > 1e-3:
+            assert float((gs[k] - ref).norm() / ref.norm()) < 2e-4, k
+
+
 def test_schedule_choices_golden(golden):
     """main.py:51-57,71-81: utils.generate_random consumes the two global generators exactly like the reference (values AND generator
     positions afterwards), and the trainer's mask_ratio_for / apply_schedules make the loop's choices (table entry, random draw,
