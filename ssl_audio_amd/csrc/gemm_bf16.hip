@@ -506,10 +506,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
       // (as in the ring kernel) the wave's whole aux_in block is requested before the first store
       const int nb = n0 + wc * 64;
       uint4 auxv[16];
+      {   // buffer loads: one per-lane offset, the row block in an SGPR, rows past M read as zeros (see staged_store_bf16)
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.aux_in, nb < p.N ? (uint32_t)((((int64_t)p.M - 1) * p.ldaux + p.N) * 2) : 0u);
+        const uint32_t ld2 = (uint32_t)p.ldaux * 2u;
+        const uint32_t voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)(lane & 7) * 16u;
+        const uint32_t soff = (uint32_t)(m0 + wr * 128) * ld2 + (uint32_t)nb * 2u;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = m0 + wr * 128 + q * 8 + (lane >> 3);
-        auxv[q] = (m < p.M && nb < p.N) ? *reinterpret_cast<const uint4*>(p.aux_in + (int64_t)m * p.ldaux + nb + (lane & 7) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        for (int q = 0; q < 16; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, soff + (uint32_t)q * 8u * ld2, 0);
+          auxv[q] = __builtin_bit_cast(uint4, v);
+        }
       }
       wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m0 + wr * 128, nb, wl, lane, nullptr, nullptr, &auxv[0]);
       wave_epilogue_compact<true, EPI>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m0 + wr * 128 + 64, nb, wl, lane, nullptr, nullptr, &auxv[8]);
@@ -1068,6 +1075,9 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   const int64_t lim = (int64_t)1 << 32;
   SA_CHECK_ARG((a_rows + 2 * BM) * a->lda * 2 < lim && (b_rows + 2 * BM) * a->ldb * 2 < lim,
                "sa_gemm_bf16: operand larger than the 4 GiB buffer-descriptor range");
+  // the compact epilogues address their bf16 outputs / inputs through buffer descriptors too (32-bit byte offsets, rows of the last tile included)
+  SA_CHECK_ARG((!a->out_bf16 || ((int64_t)a->M + 512) * a->ldo_bf16 * 2 < lim) && (!(a->aux_in || a->aux_out) || ((int64_t)a->M + 512) * a->ldaux * 2 < lim),
+               "sa_gemm_bf16: bf16 output or aux matrix larger than the 4 GiB buffer-descriptor range");
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.lda = (int)a->lda; p.ldb = (int)a->ldb;
   p.M = a->M; p.N = a->N; p.K = a->K; p.alpha = a->alpha;

@@ -229,6 +229,29 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
         *reinterpret_cast<bf16x4*>(wlds + row * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
     }
   const int ch = lane & 7;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  if (!(remap && p.row_group > 0)) {
+    // Buffer stores: ONE per-lane offset for the whole call, the row block's offset in an SGPR, rows past M dropped by the resource's
+    // bounds check -- no per-store 64-bit address arithmetic, compares or exec masks (they were 40 % of this epilogue's VALU issue).
+    // (the host checks that the output spans less than 4 GiB, as it does for the operands)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(dst, (uint32_t)((((int64_t)p.M - 1) * ld + p.N) * 2));
+    const uint32_t ld2 = (uint32_t)ld * 2u;
+    const uint32_t voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)ch * 16u;
+    uint32_t soff = (uint32_t)m_base * ld2 + (uint32_t)n_base * 2u;
+    const bool nt = p.nt_store != 0;
+#pragma unroll
+    for (int it = 0; it < 2 * NI; ++it) {
+      const int r = it * 8 + (lane >> 3);
+      const uint4 q = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
+                          : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
+      const u32x4 val = {q.x, q.y, q.z, q.w};
+      // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels
+      if (nt) __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, 0);
+      soff += 8u * ld2;
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 2 * NI; ++it) {
     const int r = it * 8 + (lane >> 3);
@@ -236,17 +259,22 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
     const uint4 val = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
                           : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
     if (m < p.M) {
-      const int64_t orow = (remap && p.row_group > 0) ? (int64_t)m + m / p.row_group + 1 : (int64_t)m;
-      if (p.nt_store == 2) {
-        asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));     // timing experiment: no global store at all
-      } else if (p.nt_store) {   // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels: streaming stores that do not displace the operands in L2
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dst + orow * ld + n_base + ch * 8));
-      } else {
-        *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
-      }
+      const int64_t orow = (int64_t)m + m / p.row_group + 1;
+      *reinterpret_cast<uint4*>(dst + orow * ld + n_base + ch * 8) = val;
     }
   }
+}
+
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: four v_add_f32 with a DPP operand -- lane ^ 1,
+// lane ^ 2 inside a quad, then the mirrored half row and the mirrored row, whose lanes already hold their quad's / half row's sum.
+// Same additions in the same order as the xor butterfly `t += __shfl_xor(t, o)` for o = 1, 2, 4, 8 (bit-identical), without its four
+// ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float row16_sum(float t) {
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xF, 0xF, true));   // row_mirror
+  return t;
 }
 
 // Mirror of staged_store_bf16 for an epilogue INPUT: a row-per-lane read of aux_in touches 16 rows x 32 B per instruction (a quarter
@@ -364,9 +392,8 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
         for (int r = 0; r < 4; ++r) {
           float t = 0.f;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+          for (int i = 0; i < NI; ++i) t += acc[i][j][r];      // rows past M: zero operand rows times a zero-filled aux row, exactly 0
+          t = row16_sum(t);
           if constexpr (CSM == 2) t += csacc[j][r];
           cs[r] = t;
           if constexpr (CSM == 1) csacc[j][r] = t;
@@ -459,8 +486,7 @@ __device__ __forceinline__ void wave_epilogue_64x64(const GemmParams& p, f32x4 (
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) t += (m_base + i * 16 + c < p.M) ? acc[i][j][r] : 0.f;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+        t = row16_sum(t);
         cs[j][r] = t;
       }
     if (c == 0) {
