@@ -80,9 +80,10 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 // GELU(x) and GELU'(x) from one exponential and one reciprocal (forward fc1 with act = 3 stores the derivative for the backward)
 __device__ __forceinline__ void gelu_pair(float x, float& y, float& dy) {
-  const float az = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  const float e = __builtin_amdgcn_exp2f(az * az * -1.44269504088896340736f);     // exp(-x^2 / 2)
+  // t = 1 / (1 + p |x| / sqrt 2) straight from x (one fma with an |.| source modifier), exp(-x^2 / 2) from x * x: the two products
+  // pack across neighbouring elements (v_pk_mul_f32), which the |x| / sqrt 2 intermediate did not
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
+  const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);     // exp(-x^2 / 2)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
@@ -95,9 +96,8 @@ __device__ __forceinline__ void gelu_pair(float x, float& y, float& dy) {
 // GELU'(x) = Phi(x) + x * phi(x).  erf(x / sqrt 2) needs exp(-x^2 / 2), which is also phi(x) up to a constant: one v_exp and one
 // v_rcp per element instead of three transcendentals (the fc2-dgrad epilogue evaluates this 128 times per lane per tile).
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float az = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  const float e = __builtin_amdgcn_exp2f(az * az * -1.44269504088896340736f);     // exp(-x^2 / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
+  const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);     // exp(-x^2 / 2)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
