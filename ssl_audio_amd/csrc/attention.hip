@@ -94,7 +94,10 @@ __device__ __forceinline__ bf16x8 scale_frag(const bf16x8& x, float c) {
 }
 
 // =====================================================================================================
-template <int NMAX>
+// FULL: the sequence fills every 16-key tile and 32-key step of the instantiation (N > NMAX - 16: 249 of 256, 501 of 512 -- the 10 s
+// clips), so the per-tile "is this tile in range" tests are compile-time true: in the unrolled loops they had become ~180 selects and
+// moves per query tile (a third of the kernel's VALU issue) next to the ~320 the softmax itself needs.
+template <int NMAX, bool FULL>
 __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
                                                           int nq, float scale, bf16_t* __restrict__ out, int ldo, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,37 +113,42 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
   const uint32_t bytes = (uint32_t)(((total_rows - row_base - 1) * ld + 3 * C) * 2);
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
 
-  const int nkt = (N + 15) >> 4;           // 16-key tiles
-  const int nks = (N + 31) >> 5;           // 32-key steps for P.V
+  const int nkt = FULL ? NKT : (N + 15) >> 4;           // 16-key tiles
+  const int nks = FULL ? NKS : (N + 31) >> 5;           // 32-key steps for P.V
+  const int g = lane >> 4, c = lane & 15;
+  const int nqt = (nq + 15) >> 4;            // only the first nq queries of each sequence are wanted (nq = N normally)
+  // Q fragments of a query tile (Y operand: k = d), one tile ahead: the first tile's are requested in front of the K / V staging, the
+  // next tile's as soon as the current tile's scores are done with the registers -- a query tile no longer starts with a global round trip
+  auto load_q = [&](int qt, bf16x8 (&q)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t voff = ((uint32_t)(qt * 16 + c) * (uint32_t)ld + (uint32_t)(h * HD + 32 * ks + 8 * g)) * 2u;
+      q[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    }
+  };
+  bf16x8 qf[2];
+  if (wave < nqt) load_q(wave, qf);
   stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane, NW_FWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane, NW_FWD);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int g = lane >> 4, c = lane & 15;
-  const int nqt = (nq + 15) >> 4;            // only the first nq queries of each sequence are wanted (nq = N normally)
-  f32x4 kbias;                               // accumulator start of the last key tile: -inf on keys >= N, else 0
-#pragma unroll
-  for (int r = 0; r < 4; ++r) kbias[r] = ((nkt - 1) * 16 + 4 * g + r >= N) ? -INFINITY : 0.f;
+  // accumulator start of the last key tile: -inf on keys >= N, else 0 -- rebuilt per query tile from ONE live register (the lane's
+  // first padded element; four live registers here were spilled in the FULL instantiation, which runs at the 128-register cap)
+  int pad_from = N - (nkt - 1) * 16 - 4 * g;
   for (int qt = wave; qt < nqt; qt += NW_FWD) {
-    // Q fragments for this lane's query (Y operand: k = d)
     const int query = qt * 16 + c;
-    bf16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t voff = ((uint32_t)query * (uint32_t)ld + (uint32_t)(h * HD + 32 * ks + 8 * g)) * 2u;
-      auto raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-      qf[ks] = __builtin_bit_cast(bf16x8, raw);
-    }
     // S^T tiles: st[kt][r] = score(key = 16*kt + 4*g + r, query)
     f32x4 st[NKT];
     float mx = -INFINITY;
-    f32x4 kb = kbias;                                  // opaque copy: keeps the 16 per-tile selects below from being hoisted
-    asm volatile("" : "+v"(kb));                       // out of the query-tile loop (64 live VGPRs -> spills)
+    asm volatile("" : "+v"(pad_from));                 // opaque: keeps the selects below inside the query-tile loop
+    f32x4 kb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kb[r] = (r >= pad_from) ? -INFINITY : 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
+      if (FULL || kt < nkt) {
         if (kt == nkt - 1) st[kt] = kb;                // padding keys start at -inf: the MFMA accumulate keeps them there
         st[kt] = MFMA16(row_frag(Kimg, kt * 16, 0, lane), qf[0], st[kt]);
         st[kt] = MFMA16(row_frag(Kimg, kt * 16, 1, lane), qf[1], st[kt]);
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);   // raw scores; the (positive) scale is folded into the exponent
       }
     }
+    if (qt + NW_FWD < nqt) load_q(qt + NW_FWD, qf);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
     const float mb = mx * c2;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
+      if (FULL || kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c2, -mb));   // exp2(-inf) = 0 for masked keys
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
     for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < NKS; ++ps) {
-      if (ps < nks) {
+      if (FULL || ps < nks) {
         const bf16x8 pf = pack8(st[2 * ps], st[2 * ps + 1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ot[dt] = MFMA16(tr_frag(Vimg, 32 * ps, 32 * ps + 16, dt * 16, lane), pf, ot[dt]);
@@ -442,22 +451,32 @@ extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32
   if (N <= 256) {
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HD * 2);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HD * 2);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * HD * 2);
       configured = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel<256>, dim3(S * H), dim3(64 * NW_FWD), 2 * 256 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H,
-                       N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+    if (N > 256 - 16)
+      hipLaunchKernelGGL((attn_fwd_kernel<256, true>), dim3(S * H), dim3(64 * NW_FWD), 2 * 256 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C,
+                         H, N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<256, false>), dim3(S * H), dim3(64 * NW_FWD), 2 * 256 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C,
+                         H, N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
   } else {
     static bool configured = false;
     if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 2) != hipSuccess) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 2) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * HD * 2) != hipSuccess) {
         sa_set_error("sa_attention_fwd: 128 KiB of LDS per workgroup refused");
         return 2;
       }
       configured = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel<512>, dim3(S * H), dim3(64 * NW_FWD), 2 * 512 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H,
-                       N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+    if (N > 512 - 16)
+      hipLaunchKernelGGL((attn_fwd_kernel<512, true>), dim3(S * H), dim3(64 * NW_FWD), 2 * 512 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C,
+                         H, N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<512, false>), dim3(S * H), dim3(64 * NW_FWD), 2 * 512 * HD * 2, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C,
+                         H, N, n_query, scale, (bf16_t*)out, (int)ldo, lse);
   }
   SA_LAUNCH_CHECK("sa_attention_fwd");
   return 0;
