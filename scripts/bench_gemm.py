@@ -35,7 +35,7 @@ cases = [
 ]
 for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16), ("fc1", 4 * d, d, h4, x16), ("fc2", d, 4 * d, x16, h4)]:
     out = torch.zeros(N, K, device=dev)
-    use256 = ((N + 255) // 256) * ((K + 255) // 256) >= int(os.environ.get("SA_WGRAD256_MIN", "16"))
+    use256 = ((N + 255) // 256) * ((K + 255) // 256) >= int(os.environ.get("SA_WGRAD256_MIN", "9"))
     sk = ops.pick_split_k(N, K, M, tile=256) if use256 else ops.pick_split_k(N, K, M)
     cases.append((f"wgrad TN {name} split{sk}{' 256' if use256 else ''}",
                   lambda out=out, dy=dy, xx=xx, sk=sk, use256=use256: ops.gemm(dy, xx, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=sk, tile256=use256), 2.0 * M * N * K))

@@ -172,15 +172,16 @@ def grad_target(p):
     return t, t
 
 
-WGRAD256_MIN_TILES = int(os.environ.get("SA_WGRAD256_MIN", "16"))
+WGRAD256_MIN_TILES = int(os.environ.get("SA_WGRAD256_MIN", "9"))
 
 
 def _wgrad(dY16, X16, out):
     """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip)."""
     N, K = out.shape
     rows = dY16.shape[0]
-    # measured (scripts/bench_gemm.py): with >= 16 output tiles of 256 x 256 the one-workgroup-per-CU 256^2 split-K tile wins
-    # (halved operand traffic, the long reduction hides its epilogue); narrower outputs stay on the 128^2 tile
+    # measured (scripts/bench_gemm.py): with >= 9 output tiles of 256 x 256 (d = 768: every block weight) the one-workgroup-per-CU
+    # 256^2 split-K tile wins (halved operand traffic, the long reduction hides its epilogue; proj at 9 tiles x 28 slices: 102 vs
+    # 110 us); narrower outputs (ViT-T) stay on the 128^2 tile
     if ((N + 255) // 256) * ((K + 255) // 256) >= WGRAD256_MIN_TILES and rows >= 4096:
         split = ops.pick_split_k(N, K, rows, tile=256)
         if split > 1:
