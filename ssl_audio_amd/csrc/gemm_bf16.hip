@@ -77,6 +77,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   const int kt_end = min(ksteps, kt_begin + chunk);
   if (kt_begin >= kt_end) return;  // (only possible for split_k > 1: nothing to add; the deterministic reduce skips empty slices)
 
+  constexpr bool HID = !(A_KM && B_KM);    // kernels with a transposing-read operand hide their LDS-DMA from the compiler (lds_dma16)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
 
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // LDS layout: [buffer 0: A tile | B tile][buffer 1: A tile | B tile]
-  stage_tile<A_KM>(ra, smem, p.lda, m0, kt_begin * BK, wave, lane);
-  stage_tile<B_KM>(rb, smem + TILE_BYTES, p.ldb, n0, kt_begin * BK, wave, lane);
+  stage_tile<A_KM, 4, HID>(ra, smem, p.lda, m0, kt_begin * BK, wave, lane);
+  stage_tile<B_KM, 4, HID>(rb, smem + TILE_BYTES, p.ldb, n0, kt_begin * BK, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     if (kt + 1 < kt_end) {
       char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile<A_KM>(ra, nxt, p.lda, m0, (kt + 1) * BK, wave, lane);
-      stage_tile<B_KM>(rb, nxt + TILE_BYTES, p.ldb, n0, (kt + 1) * BK, wave, lane);
+      stage_tile<A_KM, 4, HID>(ra, nxt, p.lda, m0, (kt + 1) * BK, wave, lane);
+      stage_tile<B_KM, 4, HID>(rb, nxt + TILE_BYTES, p.ldb, n0, (kt + 1) * BK, wave, lane);
     }
     const char* ta = smem + cur * 2 * TILE_BYTES;
     const char* tb = ta + TILE_BYTES;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const int kt0 = SPLIT ? ks_id * chunk : 0;
   const int ksteps = SPLIT ? min(ksteps_all - kt0, chunk) : ksteps_all;
   if (ksteps <= 0) return;
+  constexpr bool HID = !(A_KM && B_KM);    // kernels with a transposing-read operand hide their LDS-DMA from the compiler (lds_dma16)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
 
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stage_all = [&](char* buf, int k0) {
-    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
-    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+    stage_tile<A_KM, 8, HID>(ra, buf, p.lda, m0, k0, wave, lane);
+    stage_tile<A_KM, 8, HID>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+    stage_tile<B_KM, 8, HID>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+    stage_tile<B_KM, 8, HID>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
   };
 
   stage_all(smem, kt0 * BK);
@@ -203,8 +205,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   int cur = 0;
   for (int kt = 0; kt < ksteps; ++kt) {
-    // the second wave row requests its share of the next K-tile mid-step (see gemm256_persist_kernel): 12-14 % on the wgrad shapes
-    const bool late = p.stagger && wr == 1;
+    // the second wave row requests its share of the next K-tile mid-step (see gemm256_persist_kernel).  Only with compiler-visible
+    // requests: there the mid-step position staggered the drain hipcc puts behind them (lds_dma16) between a SIMD's two waves, 12-14 %
+    // on the wgrad shapes; with hidden requests there is no drain and requesting at the top is 3-5 % faster still
+    const bool late = !HID && p.stagger && wr == 1;
     if (kt + 1 < ksteps && !late) stage_all(smem + (cur ^ 1) * BUF, (kt0 + kt + 1) * BK);
     const char* ta = smem + cur * BUF + wr * TILE_BYTES;                 // this wave's A half-tile (128 rows)
     const char* tb = smem + cur * BUF + (2 + (wc >> 1)) * TILE_BYTES;    // this wave's B half-tile
@@ -391,13 +395,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     n0 = (within / gm) * 256;
   };
   const int ksteps = (p.K + BK - 1) / BK;
+  constexpr bool HID = !(A_KM && B_KM);    // kernels with a transposing-read operand hide their LDS-DMA from the compiler (lds_dma16)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
   auto stage_all = [&](char* buf, int m0, int n0, int k0) {
-    stage_tile<A_KM, 8>(ra, buf, p.lda, m0, k0, wave, lane);
-    stage_tile<A_KM, 8>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
-    stage_tile<B_KM, 8>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
+    stage_tile<A_KM, 8, HID>(ra, buf, p.lda, m0, k0, wave, lane);
+    stage_tile<A_KM, 8, HID>(ra, buf + TILE_BYTES, p.lda, m0 + 128, k0, wave, lane);
+    stage_tile<B_KM, 8, HID>(rb, buf + 2 * TILE_BYTES, p.ldb, n0, k0, wave, lane);
+    stage_tile<B_KM, 8, HID>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
   };
 
   int t = lid;
@@ -621,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
     kt0 = ks_id * chunk;
     nk = min(ksteps_all - kt0, chunk);
   };
+  constexpr bool HID = !(A_KM && B_KM);    // kernels with a transposing-read operand hide their LDS-DMA from the compiler (lds_dma16)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
 
@@ -654,10 +660,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring_kernel(const GemmParams p
   };
   // piece i (0..3) of a half: this wave's instruction (i & 1) of 16-KiB tile (i >> 1)
   auto issue_a = [&](const HalfReq& h, int i) {
-    stage_one_v<A_KM>(ra, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.lda, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
+    stage_one_v<A_KM, HID>(ra, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.lda, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
   };
   auto issue_b = [&](const HalfReq& h, int i) {
-    stage_one_v<B_KM>(rb, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.ldb, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
+    stage_one_v<B_KM, HID>(rb, smem + h.slot * HALF + (i >> 1) * TILE_BYTES, p.ldb, h.row0 + (i >> 1) * 128, h.k0, wave * 2 + (i & 1), lane, h.valid);
   };
   auto request_half = [&]() {                          // burst form (prologue, after an epilogue)
     const bool is_a = rside == 0;

@@ -64,9 +64,26 @@ constexpr int NTHREADS = 256;
 // read) land on 8 distinct 32-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
 
+// One LDS-DMA request (1 KiB: 16 bytes per lane, lane-linear in LDS from `lds`).  HIDDEN = true issues it through inline assembly:
+// hipcc puts an `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 (the transposing read of the k-strided operand layouts) that
+// follows a builtin LDS-DMA, because it cannot tell that the request targets the OTHER stage -- which drains the K-tile just requested
+// before the current one is consumed, i.e. serialises what the double buffer is there to overlap (plain ds_read_b128 is not affected).
+// A request the compiler does not see gets no such wait; the kernels' own `s_waitcnt vmcnt` + barrier still order it against the
+// reads of its stage, and the compiler's counted waits for other memory operations can only over-wait (vmcnt retires in order).
+template <bool HIDDEN>
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff) {
+  if constexpr (HIDDEN) {
+    // (the low 32 bits of a generic pointer into LDS are the LDS byte address: the shared aperture lives in the high half)
+    const uint32_t addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(addr), "v"(voff), "s"(rsrc) : "m0");
+  } else {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds), 16, voff, 0, 0, 0);
+  }
+}
+
 // ---- HBM -> LDS staging of one operand tile ---------------------------------------------------------
 // k-major operand: tile = 128 rows x 64 k (128 B rows).  16 wave-instructions of 1 KiB (8 rows each).
-template <bool KMAJOR, int NWAVES = 4>
+template <bool KMAJOR, int NWAVES = 4, bool HIDDEN = false>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0,
                                            int wave, int lane) {
   constexpr int PER_WAVE = 16 / NWAVES;
@@ -77,7 +94,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
       const int row = q * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ (row & 7);
       const uint32_t voff = ((uint32_t)(row0_or_col0 + row) * (uint32_t)ld + (uint32_t)(k0 + chunk * 8)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+      lds_dma16<HIDDEN>(rsrc, lds_tile + q * 1024, voff);
     }
   } else {
     // k-strided operand: tile = 64 k-rows x 128 cols (256 B rows).  16 wave-instructions (4 k-rows each).
@@ -87,14 +104,14 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
       const int krow = q * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ ks_swz(krow);
       const uint32_t voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+      lds_dma16<HIDDEN>(rsrc, lds_tile + q * 1024, voff);
     }
   }
 }
 
 // one wave-instruction (number q of 16) of stage_tile, with a validity flag: lets a kernel space its LDS-DMA requests out between
 // MFMAs; an invalid request goes out of range (zero fill, no traffic) so vmcnt bookkeeping stays exact
-template <bool KMAJOR>
+template <bool KMAJOR, bool HIDDEN = false>
 __device__ __forceinline__ void stage_one_v(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int row0_or_col0, int k0, int q, int lane, bool valid) {
   uint32_t voff;
   if constexpr (KMAJOR) {
@@ -107,7 +124,7 @@ __device__ __forceinline__ void stage_one_v(__amdgpu_buffer_rsrc_t rsrc, char* l
     voff = ((uint32_t)(k0 + krow) * (uint32_t)ld + (uint32_t)(row0_or_col0 + chunk * 8)) * 2u;
   }
   voff = valid ? voff : 0xFFFFFFF0u;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + q * 1024), 16, voff, 0, 0, 0);
+  lds_dma16<HIDDEN>(rsrc, lds_tile + q * 1024, voff);
 }
 
 // ---- LDS -> register fragment for one 16-wide sub-tile and one 32-deep k-step -------------------------

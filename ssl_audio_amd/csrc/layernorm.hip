@@ -83,15 +83,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mean = mean_in[row], rstd = rstd_in[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
-    float4 xh[MAXV], gd[MAXV], rr[MAXV];
+    float4 xh[MAXV], gd[MAXV];
     float s1 = 0.f, s2 = 0.f;
-    // the residual gradient is requested together with the row's other inputs (it is only consumed after the two row reductions:
-    // loading it there put a second global round trip into every row)
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
-      rr[i] = (dres && c < nv) ? reinterpret_cast<const float4*>(dres + (int64_t)row * lddres)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + i * 64;
@@ -123,7 +116,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
         o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
         o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
         o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
-        o.x += rr[i].x; o.y += rr[i].y; o.z += rr[i].z; o.w += rr[i].w;
+        if (dres) {
+          const float4 r = reinterpret_cast<const float4*>(dres + (int64_t)row * lddres)[c];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         if (dx_f32) reinterpret_cast<float4*>(dx_f32 + (int64_t)row * lddx)[c] = o;
         if (dx_bf16) {
           bf16x4 h = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};

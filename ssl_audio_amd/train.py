@@ -90,7 +90,6 @@ class FlatState:
         # step is data, not a kernel argument, so a captured step (HIP graph) replays with the current values.  Staged through pinned host
         # memory by one small async copy per step.
         self.hyper = torch.zeros(2, 4, device=device)
-        self._hyper_host = torch.zeros(2, 4).pin_memory() if torch.device(device).type == "cuda" else torch.zeros(2, 4)
         self.sync = None           # the GradSync that reduces self.grads over ranks (engine.block_done_hook finds it through the sinks)
 
     def bind_bf16(self):
@@ -110,9 +109,13 @@ class FlatState:
         self.step_count += 1
         t = self.step_count
         c1, c2 = 1.0 - betas[0] ** t, 1.0 - betas[1] ** t
-        h = self._hyper_host
-        h[0, 0], h[0, 1], h[0, 2] = lr, 1.0 / c1, 1.0 / math.sqrt(c2)
-        h[1, 0], h[1, 1], h[1, 2] = (lr if lr_nodecay is None else lr_nodecay), 1.0 / c1, 1.0 / math.sqrt(c2)
+        # a FRESH pinned staging block per step: the copy is asynchronous and the host runs steps ahead of the stream, so one reused
+        # block would be overwritten with step t + 1's values before step t's copy has read it (the caching host allocator keeps a
+        # block away from reuse until the copy that reads it has completed)
+        h = torch.tensor([[lr, 1.0 / c1, 1.0 / math.sqrt(c2), 0.0],
+                          [lr if lr_nodecay is None else lr_nodecay, 1.0 / c1, 1.0 / math.sqrt(c2), 0.0]], dtype=torch.float32)
+        if self.hyper.is_cuda:
+            h = h.pin_memory()
         self.hyper.copy_(h, non_blocking=True)
 
     def adamw_staged(self, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, skip_flag=None):
