@@ -1081,9 +1081,6 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   const int64_t lim = (int64_t)1 << 32;
   SA_CHECK_ARG((a_rows + 2 * BM) * a->lda * 2 < lim && (b_rows + 2 * BM) * a->ldb * 2 < lim,
                "sa_gemm_bf16: operand larger than the 4 GiB buffer-descriptor range");
-  // the compact epilogues address their bf16 outputs / inputs through buffer descriptors too (32-bit byte offsets, rows of the last tile included)
-  SA_CHECK_ARG((!a->out_bf16 || ((int64_t)a->M + 512) * a->ldo_bf16 * 2 < lim) && (!(a->aux_in || a->aux_out) || ((int64_t)a->M + 512) * a->ldaux * 2 < lim),
-               "sa_gemm_bf16: bf16 output or aux matrix larger than the 4 GiB buffer-descriptor range");
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.lda = (int)a->lda; p.ldb = (int)a->ldb;
   p.M = a->M; p.N = a->N; p.K = a->K; p.alpha = a->alpha;
@@ -1101,7 +1098,11 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   {
     const bool al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; }(a->out_bf16) && [](const void* q) { return ((uintptr_t)q & 15) == 0; }(a->aux_out) &&
                       [](const void* q) { return ((uintptr_t)q & 7) == 0; }(a->aux_in);
-    const bool base_ok = !(es_env && es_env[0] == '0') && a->split_k == 1 && a->row_group == 0 && a->res_mod == 0 && !a->accumulate && a->N % 64 == 0 && al16;
+    // the compact epilogues address their bf16 outputs / inputs through buffer descriptors (32-bit byte offsets, the rows of the last
+    // tile included): matrices past that range take the general epilogue
+    const int64_t lim32 = (int64_t)1 << 32;
+    const bool desc_ok = (!a->out_bf16 || ((int64_t)a->M + 512) * a->ldo_bf16 * 2 < lim32) && (!(a->aux_in || a->aux_out) || ((int64_t)a->M + 512) * a->ldaux * 2 < lim32);
+    const bool base_ok = !(es_env && es_env[0] == '0') && a->split_k == 1 && a->row_group == 0 && a->res_mod == 0 && !a->accumulate && a->N % 64 == 0 && al16 && desc_ok;
     const bool bf16_only = a->out_bf16 && !a->out_f32 && a->ldo_bf16 % 8 == 0 && !a->residual;
     if (base_ok && bf16_only && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out) p.epi_kind = 1;
     else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;   // (not dispatched: spills)
