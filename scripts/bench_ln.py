@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl_audio_amd import ops
 
-M, D = 128 * 251, 768
+M, D = int(os.environ.get("SA_LN_M", 128 * 251)), int(os.environ.get("SA_LN_D", 768))
 dev = "cuda"
 x = torch.randn(M, D, device=dev)
 dyb = torch.randn(M, D, device=dev).bfloat16()

@@ -8,45 +8,67 @@ namespace {
 
 constexpr int MAXV_LIMIT = 8;  // float4 per lane -> D <= 64 * 4 * 8 = 2048 (kernels are instantiated for 1, 2, 3, 4, 8)
 
+// Sum over the LPR lanes that share a row (LPR = 64: the whole wave; 32 / 16: two / four rows per wave, the narrow-model layouts).
+// 16 lanes are one DPP row: four v_add_f32 with a DPP operand (quad xor 1, xor 2, mirrored half row, mirrored row).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (LPR == 64) {
+    return wave_sum(v);
+  } else {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    if constexpr (LPR == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+  }
+}
+
 // y = (x - mean) * rstd * gamma + beta ; writes bf16 and/or fp32, saves mean / rstd per row
-template <int MAXV>
+// RPW rows per wave (1, 2 or 4): a row is spread over LPR = 64 / RPW lanes, lane `sub` owning the float4 columns sub + i * LPR.  Narrow
+// rows (D = 192: 48 float4) left a quarter of the wave idle and one 768-byte row in flight per wave; four rows per wave use every lane
+// and keep four rows' loads in flight.
+template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y_bf16,
                                                      float* __restrict__ y_f32, int64_t ldy, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int D, float eps) {
-  const int lane = threadIdx.x & 63;
+  constexpr int LPR = 64 / RPW;
+  const int lane = threadIdx.x & 63, sub = lane & (LPR - 1), rsel = lane / LPR;
   const int nv = D >> 2;  // float4 per row
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+  for (int rb = blockIdx.x * 4 + (threadIdx.x >> 6); rb * RPW < M; rb += gridDim.x * 4) {
+    const int row = rb * RPW + rsel;
+    const bool live = row < M;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)(live ? row : 0) * ldx);
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
+      const int c = sub + i * LPR;
       if (c < nv) {
         v[i] = xr[c];
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       }
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = group_sum<LPR>(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
+      const int c = sub + i * LPR;
       if (c < nv) {
         const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
         q += (a * a + b * b) + (cc * cc + d * d);
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) {
+    const float rstd = rsqrtf(group_sum<LPR>(q) / (float)D + eps);
+    if (sub == 0 && live) {
       if (mean_out) mean_out[row] = mean;
       if (rstd_out) rstd_out[row] = rstd;
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
+      const int c = sub + i * LPR;
+      if (c < nv && live) {
         const float4 g = reinterpret_cast<const float4*>(gamma)[c];
         const float4 b = reinterpret_cast<const float4*>(beta)[c];
         float4 o;
@@ -67,28 +89,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum dy*xhat ; dbeta += sum dy
 // dy arrives as bf16 (from a dgrad GEMM) or fp32 (from the loss side).  Each lane owns fixed columns, so its
 // dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + a workspace row at the end.
-template <typename DY, int MAXV>
+template <typename DY, int MAXV, int RPW>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
                                                      float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx,
                                                      float* __restrict__ ws, int M, int D) {
+  constexpr int LPR = 64 / RPW;                          // lanes per row (see ln_fwd_kernel)
   __shared__ float red[4 * 64 * 4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & (LPR - 1), rsel = lane / LPR;
   const int nv = D >> 2;
   float4 ag[MAXV], ab[MAXV], ax[MAXV];   // column partials: dgamma, dbeta, and sum of the OUTPUT dx (= bias gradient of the
 #pragma unroll                           // Linear whose output gradient dx is: proj for LN2, the previous block's fc2 for LN1)
   for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+  for (int rb = blockIdx.x * 4 + wave; rb * RPW < M; rb += gridDim.x * 4) {
+    const int row = rb * RPW + rsel;
+    const bool live = row < M;
+    const int rowc = live ? row : 0;
+    const float mean = mean_in[rowc], rstd = rstd_in[rowc];
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)rowc * ldx);
     float4 xh[MAXV], gd[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
+      const int c = sub + i * LPR;
+      if (c < nv && live) {
         const float4 xv = xr[c];
         float4 d;
         if constexpr (sizeof(DY) == 2) {
@@ -106,11 +132,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
         s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
       }
     }
-    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    const float m1 = group_sum<LPR>(s1) / (float)D, m2 = group_sum<LPR>(s2) / (float)D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
+      const int c = sub + i * LPR;
+      if (c < nv && live) {
         float4 o;
         o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
         o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
@@ -132,22 +158,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
   if (ws == nullptr) return;
   // Column partials leave the block through a workspace ([kind][block][D]); ln_bwd_reduce_kernel sums them.  (Atomics on
   // 3*D addresses from ~1000 blocks are resolved memory-side across the 8 XCDs and cost more than the whole streaming pass.)
+  // The block's 4 waves x RPW row groups each hold a partial of column chunk (sub, i): they meet in LDS, LPR columns at a time.
   const int nblk = gridDim.x;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (i * 64 >= nv) break;
+    const int c = sub + i * LPR;
+    if (i * LPR >= nv) break;
 #pragma unroll
     for (int kind = 0; kind < 3; ++kind) {
       __syncthreads();
       reinterpret_cast<float4*>(red)[wave * 64 + lane] = kind == 0 ? ag[i] : kind == 1 ? ab[i] : ax[i];
       __syncthreads();
-      if (wave == 0 && c < nv) {
-        float4 t = reinterpret_cast<float4*>(red)[lane];
-        for (int w = 1; w < 4; ++w) {
-          const float4 u = reinterpret_cast<float4*>(red)[w * 64 + lane];
-          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
+      if (wave == 0 && rsel == 0 && c < nv) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int r = 0; r < RPW; ++r) {
+            const float4 u = reinterpret_cast<float4*>(red)[w * 64 + r * LPR + sub];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+          }
         reinterpret_cast<float4*>(ws + ((int64_t)kind * nblk + blockIdx.x) * D)[c] = t;
       }
     }
@@ -186,13 +215,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
 }
 
-inline int ln_bwd_grid(int M) {   // fewer, fatter blocks than forward: every block ends with a 3*D partial
-  const int g = (M + 3) / 4;
+inline int ln_rpw(int D) {   // rows per wave: the widest layout whose LPR = 64 / RPW lanes still hold a row in <= 4 float4 each
+  const int nv = D / 4;
+  return nv <= 16 * 4 && nv % 16 == 0 && nv <= 64 ? 4 : (nv <= 32 * 4 && nv % 32 == 0 && nv <= 128 ? 2 : 1);
+}
+
+inline int ln_bwd_grid(int M, int D = 2048) {   // fewer, fatter blocks than forward: every block ends with a 3*D partial
+  const int g = (M + 4 * ln_rpw(D) - 1) / (4 * ln_rpw(D));
   return g > 1024 ? 1024 : g;
 }
 
-inline int ln_grid(int M) {
-  const int want = (M + 3) / 4;
+inline int ln_grid(int M, int D) {
+  const int want = (M + 4 * ln_rpw(D) - 1) / (4 * ln_rpw(D));
   return want < 2048 ? want : 2048;
 }
 
@@ -203,17 +237,20 @@ extern "C" int sa_layernorm_fwd(const float* x, int64_t ldx, const float* gamma,
   SA_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32), "sa_layernorm_fwd: null pointer");
   SA_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXV_LIMIT, "sa_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXV_LIMIT);
   SA_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "sa_layernorm_fwd: leading dims must be multiples of 4");
-  const int nv = (D / 4 + 63) / 64;
-#define SA_LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, \
-                                        (bf16_t*)y_bf16, y_f32, ldy, mean, rstd, M, D, eps)
-  if (nv <= 1) SA_LN_FWD(1); else if (nv == 2) SA_LN_FWD(2); else if (nv == 3) SA_LN_FWD(3); else if (nv == 4) SA_LN_FWD(4); else SA_LN_FWD(8);
+  const int rpw = ln_rpw(D);
+  const int nv = (D / 4 + 64 / rpw - 1) / (64 / rpw);        // float4 per lane
+#define SA_LN_FWD(V, R) hipLaunchKernelGGL((ln_fwd_kernel<V, R>), dim3(ln_grid(M, D)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, \
+                                           (bf16_t*)y_bf16, y_f32, ldy, mean, rstd, M, D, eps)
+  if (rpw == 4) { if (nv <= 1) SA_LN_FWD(1, 4); else if (nv == 2) SA_LN_FWD(2, 4); else if (nv == 3) SA_LN_FWD(3, 4); else SA_LN_FWD(4, 4); }
+  else if (rpw == 2) { if (nv <= 1) SA_LN_FWD(1, 2); else if (nv == 2) SA_LN_FWD(2, 2); else if (nv == 3) SA_LN_FWD(3, 2); else SA_LN_FWD(4, 2); }
+  else if (nv <= 1) SA_LN_FWD(1, 1); else if (nv == 2) SA_LN_FWD(2, 1); else if (nv == 3) SA_LN_FWD(3, 1); else if (nv == 4) SA_LN_FWD(4, 1); else SA_LN_FWD(8, 1);
 #undef SA_LN_FWD
   SA_LAUNCH_CHECK("sa_layernorm_fwd");
   return 0;
 }
 
 extern "C" int64_t sa_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-  return (int64_t)3 * ln_bwd_grid(M) * D * (int64_t)sizeof(float);
+  return (int64_t)3 * ln_bwd_grid(M, D) * D * (int64_t)sizeof(float);
 }
 
 extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
@@ -224,15 +261,19 @@ extern "C" int sa_layernorm_bwd(const void* dy, int32_t dy_is_bf16, int64_t lddy
   SA_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0), "sa_layernorm_bwd: leading dims must be multiples of 4");
   const bool sums = dgamma || dbeta || dxsum;
   SA_CHECK_ARG(!sums || workspace, "sa_layernorm_bwd: column sums need a workspace of sa_layernorm_bwd_workspace_bytes(M, D)");
-  const int grid = ln_bwd_grid(M);
+  const int grid = ln_bwd_grid(M, D);
   float* ws = sums ? workspace : nullptr;
-  const int nv = (D / 4 + 63) / 64;
-#define SA_LN_BWD(T, V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy, x, ldx, \
-                                           gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, ws, M, D)
-#define SA_LN_BWD_V(T) do { if (nv <= 1) SA_LN_BWD(T, 1); else if (nv == 2) SA_LN_BWD(T, 2); else if (nv == 3) SA_LN_BWD(T, 3); \
-                            else if (nv == 4) SA_LN_BWD(T, 4); else SA_LN_BWD(T, 8); } while (0)
+  const int rpw = ln_rpw(D);
+  const int nv = (D / 4 + 64 / rpw - 1) / (64 / rpw);        // float4 per lane
+#define SA_LN_BWD(T, V, R) hipLaunchKernelGGL((ln_bwd_kernel<T, V, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, lddy, x, ldx, \
+                                              gamma, mean, rstd, dres, lddres, dx_f32, (bf16_t*)dx_bf16, lddx, ws, M, D)
+#define SA_LN_BWD_R(T, R) do { if (nv <= 1) SA_LN_BWD(T, 1, R); else if (nv == 2) SA_LN_BWD(T, 2, R); else if (nv == 3) SA_LN_BWD(T, 3, R); \
+                               else SA_LN_BWD(T, 4, R); } while (0)
+#define SA_LN_BWD_V(T) do { if (rpw == 4) SA_LN_BWD_R(T, 4); else if (rpw == 2) SA_LN_BWD_R(T, 2); else if (nv <= 4) SA_LN_BWD_R(T, 1); \
+                            else SA_LN_BWD(T, 8, 1); } while (0)
   if (dy_is_bf16) SA_LN_BWD_V(bf16_t); else SA_LN_BWD_V(float);
 #undef SA_LN_BWD_V
+#undef SA_LN_BWD_R
 #undef SA_LN_BWD
   SA_LAUNCH_CHECK("sa_layernorm_bwd");
   if (sums) {

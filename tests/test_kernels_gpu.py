@@ -183,7 +183,8 @@ def test_cast_and_colsum(dev):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("M,D", [(257, 768), (64, 192), (33, 1024), (5, 64)])
+# (D <= 256: four rows per wave, D <= 512: two -- with row counts that leave the last wave partly empty)
+@pytest.mark.parametrize("M,D", [(257, 768), (64, 192), (33, 1024), (5, 64), (4099, 192), (1, 192), (403, 256), (1031, 384), (7, 512), (130, 100)])
 def test_layernorm(dev, M, D):
     x = rnd((M, D), 11, 2.0) + 0.3; g = rnd((D,), 12) * 0.2 + 1; b = rnd((D,), 13) * 0.2
     xd = x.double().requires_grad_(True); gd = g.double().requires_grad_(True); bd = b.double().requires_grad_(True)
