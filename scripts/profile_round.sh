@@ -7,7 +7,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; mkdir -p $O
 WL=${@:-vit_base_bt_10s vit_tiny_bt_10s vit_base_byol_10s vit_large_mae_10s}
-rm -f $O/gemm_traffic.json
+if [ $# -eq 0 ]; then rm -f $O/gemm_traffic.json; else cp profiles/r03_gemm_traffic.json $O/gemm_traffic.json; fi   # named workloads: refresh their entries only
 for w in $WL; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no_cpu_baseline > $O/ktrace_$w.log 2>&1 || exit 1
   cp $(ls $O/ktrace_$w/*/*kernel_stats.csv | head -1) $O/bench_${w}_kernel_stats.csv 2>/dev/null
