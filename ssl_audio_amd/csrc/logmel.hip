@@ -17,6 +17,7 @@ namespace {
 constexpr int NFFT = 1024, NC = 512, NBINS = 513, NMEL = 64;
 constexpr int FR_PER_WAVE = 4, FR_PER_BLOCK = 16;
 constexpr int XS = 72;  // LDS row stride (floats) of the exchange buffers
+constexpr int MAXLEN_CAP = 48;  // longest mel band (in bins) whose weight table is staged in LDS (64 HTK bands over 513 bins: 42)
 
 struct cpx { float re, im; };
 __device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
   __shared__ float ex_re[4][8 * XS], ex_im[4][8 * XS];   // per-wave exchange / spectrum buffers
   __shared__ float pw[4][NBINS + 3];
   __shared__ float stage[NMEL][FR_PER_BLOCK + 1];
+  __shared__ float melw_s[MAXLEN_CAP * NMEL];            // the filter table, staged once per workgroup
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int clip = blockIdx.y;
   const int tb = blockIdx.x * FR_PER_BLOCK;  // first OUTPUT frame of this block
@@ -75,38 +77,52 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
   maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  // Everything a frame needs besides its samples is the same for every frame: the window and the three twiddle sets live in registers
+  // for the wave's four frames, the filter weights in LDS.  (They used to be re-read from global memory in every frame: ~30 loads and
+  // four dependent L2 round trips per frame, with one frame in flight per wave.)
+  const bool mel_lds = maxlen <= MAXLEN_CAP;
+  if (mel_lds)
+    for (int i = threadIdx.x; i < maxlen * NMEL; i += 256) melw_s[i] = melw[i];
+  float2 win[8], twa[8], twb[8], tws[8];
+#pragma unroll
+  for (int n1 = 0; n1 < 8; ++n1) win[n1] = *reinterpret_cast<const float2*>(window + 2 * (64 * n1 + lane));
+#pragma unroll
+  for (int k1 = 1; k1 < 8; ++k1) twa[k1] = tw[(2 * lane * k1) & 1023];
+#pragma unroll
+  for (int c = 1; c < 8; ++c) twb[c] = tw[(16 * (lane & 7) * c) & 1023];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) tws[r] = tw[lane + 64 * r];
+  __syncthreads();
+  // samples of one frame: lane n2 holds x[2 (64 n1 + n2)], x[2 (64 n1 + n2) + 1], n1 = 0..7 (reflect padding at the clip's ends)
+  auto load_frame = [&](int t, float2 (&sm)[8]) {
+    const int base = t * hop - NFFT / 2;
+    const bool interior = (base >= 0) && (base + NFFT <= L);
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+      const int n = 64 * n1 + lane;
+      if (interior) sm[n1] = *reinterpret_cast<const float2*>(wv + base + 2 * n);
+      else sm[n1] = make_float2(wv[reflect_idx(base + 2 * n, L)], wv[reflect_idx(base + 2 * n + 1, L)]);
+    }
+  };
+  auto frame_live = [&](int f) { const int to = tb + w * FR_PER_WAVE + f; return (f < FR_PER_WAVE) && (to < T_out) && (to + start < n_frames); };
+  float2 smp[8], smp_next[8];
+  if (frame_live(0)) load_frame(tb + w * FR_PER_WAVE + start, smp);
 
   for (int f = 0; f < FR_PER_WAVE; ++f) {
     const int to = tb + w * FR_PER_WAVE + f;   // output frame index
     const int t = to + start;                  // source frame index (dataset crop offset)
     float result = pad_value;
     const bool live = (to < T_out) && (t < n_frames);  // wave-uniform
+    if (frame_live(f + 1)) load_frame(t + 1, smp_next);       // the next frame's samples travel while this one is transformed
     if (live) {
-      // ---- load + window: lane n2 holds z[64*n1 + n2], n1 = 0..7
+      // ---- window: lane n2 holds z[64*n1 + n2], n1 = 0..7
       cpx v[8];
-      const int base = t * hop - NFFT / 2;
-      const bool interior = (base >= 0) && (base + NFFT <= L);
 #pragma unroll
-      for (int n1 = 0; n1 < 8; ++n1) {
-        const int n = 64 * n1 + lane;
-        float s0, s1;
-        if (interior) {
-          const float2 s = *reinterpret_cast<const float2*>(wv + base + 2 * n);
-          s0 = s.x; s1 = s.y;
-        } else {
-          s0 = wv[reflect_idx(base + 2 * n, L)];
-          s1 = wv[reflect_idx(base + 2 * n + 1, L)];
-        }
-        const float2 wn = *reinterpret_cast<const float2*>(window + 2 * n);
-        v[n1] = {s0 * wn.x, s1 * wn.y};
-      }
+      for (int n1 = 0; n1 < 8; ++n1) v[n1] = {smp[n1].x * win[n1].x, smp[n1].y * win[n1].y};
       // ---- pass A: DFT8 over n1, twiddle W_512^{n2*k1} = W_1024^{2*n2*k1}
       dft8(v);
 #pragma unroll
-      for (int k1 = 1; k1 < 8; ++k1) {
-        const float2 t2 = tw[(2 * lane * k1) & 1023];
-        v[k1] = cmul(v[k1], {t2.x, t2.y});
-      }
+      for (int k1 = 1; k1 < 8; ++k1) v[k1] = cmul(v[k1], {twa[k1].x, twa[k1].y});
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) { xr[k1 * XS + lane] = v[k1].re; xi[k1 * XS + lane] = v[k1].im; }
       __builtin_amdgcn_wave_barrier();
@@ -116,10 +132,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
       for (int a = 0; a < 8; ++a) v[a] = {xr[k1 * XS + 8 * a + b], xi[k1 * XS + 8 * a + b]};
       dft8(v);
 #pragma unroll
-      for (int c = 1; c < 8; ++c) {
-        const float2 t2 = tw[(16 * b * c) & 1023];
-        v[c] = cmul(v[c], {t2.x, t2.y});
-      }
+      for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], {twb[c].x, twb[c].y});
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int c = 0; c < 8; ++c) { xr[k1 * XS + 9 * c + b] = v[c].re; xi[k1 * XS + 9 * c + b] = v[c].im; }
@@ -144,8 +157,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         const cpx e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
         const cpx dd = csub(zk, zc);
         const cpx o = {0.5f * dd.im, -0.5f * dd.re};                     // (-i/2) (Z[k] - conj(Z[N-k]))
-        const float2 t2 = tw[k];
-        const cpx xk = cadd(e, cmul(o, {t2.x, t2.y}));
+        const cpx xk = cadd(e, cmul(o, {tws[r].x, tws[r].y}));
         P[k] = xk.re * xk.re + xk.im * xk.im;
       }
       if (lane == 0) {  // Nyquist bin: X[512] = E[0] - O[0] = Re Z[0] - Im Z[0]
@@ -155,12 +167,19 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
       __builtin_amdgcn_wave_barrier();
       // ---- mel band `lane`: sum over its bin range
       float m = 0.f;
+      if (mel_lds) {
 #pragma unroll 8
-      for (int q = 0; q < maxlen; ++q) m += melw[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];   // same order of additions as before
+        for (int q = 0; q < maxlen; ++q) m += melw_s[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];   // same order of additions as before
+      } else {
+#pragma unroll 8
+        for (int q = 0; q < maxlen; ++q) m += melw[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];
+      }
       result = (logf(m + 1.1920929e-07f) - mean) * inv_std;
       __builtin_amdgcn_wave_barrier();
     }
     stage[lane][w * FR_PER_WAVE + f] = result;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) smp[n1] = smp_next[n1];
   }
   __syncthreads();
   // ---- write [64 mel][16 frames]: thread -> (mel = tid / 4, 4 consecutive frames)
