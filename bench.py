@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: clips/sec of the Barlow Twins pre-training step (10 s @ 16 kHz -> 64-mel, ViT-B, BT loss).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (RANK / WORLD_SIZE in the environment, e.g. `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`) this process IS a rank; without one it starts the ranks itself as a child
+`torch.distributed.run` (before anything here touches a GPU), forwards rank 0's JSON line and returns the child's exit code.
 
 One "step" = one pass of the whole hot path over one batch of synthetic waveforms already resident in HBM:
 log-mel frontend -> 2 augmented views -> encoder+projector fwd -> BT loss -> bwd -> grad all-reduce -> AdamW.
@@ -125,6 +129,30 @@ def cpu_baseline(workload, budget_clips=8, steps=16):
                       f"{torch.get_num_threads()} threads of {avail} visible cores (oracle/: frontend + augment + fwd/bwd + AdamW)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD process (never a re-exec; nothing
+    in this parent has touched the GPU: no torch.cuda call, no ops.lib()), the way the reference is launched -- one process per GPU
+    from torchrun's environment (utils/utils.py:335-361).  The child's stdout (rank 0's single JSON line) and stderr pass through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = [a for a in sys.argv[1:] if a != "--dry_launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["SA_BENCH_PARENT"] = str(os.getpid())
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +160,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="vit_base_bt_10s", choices=sorted(WORKLOADS))
     ap.add_argument("--batch_per_gpu", type=int, default=None)
+    ap.add_argument("--global_batch", type=int, default=None, help="STRONG scaling: this many clips in all, split over the ranks "
+                    "(BASELINE config 3's 1024); default is weak scaling at the workload's clips per GPU")
+    ap.add_argument("--dry_launch", action="store_true", help="print the child launcher command of the self-launch path and exit")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the device part of the step as ONE HIP graph (BarlowTwinsTrainer.enable_graph); "
                     "default eager: measured on MI355X / ROCm 7.2 the replay of the ~600-node graph is 1-2 % SLOWER than the eager launches, "
@@ -139,6 +170,8 @@ def main():
     ap.add_argument("--no_graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--profile_steps", type=int, default=3, help="eager steps with per-launch HIP events after the timed region (roofline)")
     args = ap.parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_launch or os.environ.get("SA_BENCH_SELF_LAUNCH") == "1"):
+        sys.exit(self_launch(args))
 
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator comes up, so
     # the process-level stdout is parked on stderr until the result is ready
@@ -158,9 +191,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.lib()                                                      # fail loudly if the HIP library is missing
+    dist_backend = torch.distributed.get_backend() if sdist.is_dist_avail_and_initialized() else None
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())      # RCCL's version (backend "nccl" IS RCCL on ROCm)
+    except Exception:  # noqa: BLE001
+        rccl_version = None
 
     model_type, seconds, bpg, mode = WORKLOADS[args.workload]
     B = args.batch_per_gpu or bpg
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global_batch {args.global_batch} does not divide over {world} ranks")
+        B = args.global_batch // world
     n_samples = int(seconds * 16000)
     extra = dict(masked_recon=True, mask=True, mask_ratio=0.75) if mode == "mae" else {}
     frames = (n_samples // 160 + 1) // 16 * 16 if mode == "mae" else n_samples // 160 + 1      # MAE: whole patches (992)
@@ -293,13 +335,16 @@ def main():
         line = {
             "metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "encoder": model_type, "clip_seconds": seconds, "n_mels": 64,
                        "clips_per_gpu": B, "global_batch": B * world, "step": "logmel+augment+fwd+bwd+allreduce+adamw" +
                        ("+ema" if mode == "byol" else ""), "hip_graph": trainer._graph is not None,
                        "profiled_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
-                       "loss": round(loss_val, 4)},
+                       "loss": round(loss_val, 4),
+                       "dist_world": sdist.get_world_size(), "dist_backend": dist_backend, "rccl_version": rccl_version,
+                       "launcher": "torch.distributed.run (self-launched child)" if os.environ.get("TORCHELASTIC_RUN_ID") is not None
+                       and os.environ.get("SA_BENCH_PARENT") else ("torch.distributed.run" if "RANK" in os.environ else "single process")},
             "roofline": {"bound": "mfma", "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
                          "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_note": traffic_note,

@@ -88,8 +88,12 @@ int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
  * the data gradients dX = dY W run in the forward (k-contiguous x k-contiguous) operand layout, measured 6-16 % faster than reading W
  * k-strided; refreshed once per optimiser step. */
 int sa_transpose_bf16(const void* src_bf16, int32_t R, int32_t C, void* dst_bf16, void* stream);
-/* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients); accumulate != 0 adds */
-int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
+/* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients of nn.Linear, models/mae.py:125-131,155 backward);
+ * accumulate != 0 adds.  ws: scratch of sa_colsum_workspace_bytes(M, N) bytes -- row slabs store their partial sums there and a
+ * second launch adds them in slab order (bit-reproducible; ABI v5).  ws == NULL: one float atomic per column per block instead
+ * (exact only up to the fp32 rounding of an arbitrary summation order). */
+int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, void* stream);
+int64_t sa_colsum_workspace_bytes(int32_t M, int32_t N);
 
 
 /* ------------------------------------------------------------------ LayerNorm (fp32 stream -> bf16/fp32)

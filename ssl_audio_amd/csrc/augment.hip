@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
 }
 
 // ---- NormalizeBatch: (X - mean) / clamp(std_unbiased, eps) over the whole [B,1,F,T] tensor
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float shift, double* __restrict__ acc) {
+// (block partials in a device global, added in block order by a one-wave launch: a fixed summation order, no atomics)
+__device__ double sumsq_partials[2 * 1024];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float shift) {
   __shared__ float red[4];
   float s = 0.f, q = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -131,8 +134,29 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   s = block_sum_256(s, red);
   q = block_sum_256(q, red);
   if (threadIdx.x == 0) {
-    atomicAdd(acc, (double)s);
-    atomicAdd(acc + 1, (double)q);
+    sumsq_partials[2 * blockIdx.x] = (double)s;
+    sumsq_partials[2 * blockIdx.x + 1] = (double)q;
+  }
+}
+
+__global__ __launch_bounds__(64) void sumsq_finish_kernel(int nblocks, double* __restrict__ acc) {
+  __shared__ double lanes[2][64];
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    s += sumsq_partials[2 * b];
+    q += sumsq_partials[2 * b + 1];
+  }
+  lanes[0][threadIdx.x] = s;
+  lanes[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int l = 0; l < 64; ++l) {
+      ts += lanes[0][l];
+      tq += lanes[1][l];
+    }
+    acc[0] = ts;
+    acc[1] = tq;
   }
 }
 
@@ -252,13 +276,10 @@ extern "C" int sa_running_norm(const float* x, int32_t channels, int64_t per_cha
 
 extern "C" int sa_normalize_batch(const float* x, float* y, int64_t n, float shift, double* workspace2, float eps, float stat_div, void* stream) {
   SA_CHECK_ARG(x && y && workspace2 && n > 1 && stat_div > 0.f, "sa_normalize_batch: bad args");
-  if (hipMemsetAsync(workspace2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess) {
-    sa_set_error("sa_normalize_batch: memset failed");
-    return 2;
-  }
   int64_t want = (n + 256 * 16 - 1) / (256 * 16);
   const int grid = (int)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, shift, workspace2);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, shift);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, workspace2);
   hipLaunchKernelGGL(normalize_apply_kernel, dim3(grid * 4), dim3(256), 0, (hipStream_t)stream, x, y, n, shift, workspace2, eps, stat_div);
   SA_LAUNCH_CHECK("sa_normalize_batch");
   return 0;

@@ -184,8 +184,13 @@ __global__ __launch_bounds__(64) void matmul_f32_kernel(const float* __restrict_
 }
 
 // ---- loss = alpha * sum_i (c_ii - 1)^2 + lambda * sum_{i != j} (c_ij [+1])^2 ; G = dL/dc   (utils/loss.py:23-30)
+// The loss scalar is summed in a fixed order (no float atomics: bit-reproducible): every block leaves its partial in bt_loss_partials and a
+// one-wave launch adds them in block order.  The partials are a device global of this library: launches that share it are ordered on
+// one stream (the loss terms of a step are), like every workspace the host side hands in.
+__device__ float bt_loss_partials[256];
+
 __global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restrict__ c, int D, float alpha, float lambda, int hsic,
-                                                           float* __restrict__ loss, float* __restrict__ G) {
+                                                           float* __restrict__ G) {
   __shared__ float red[4];
   float s = 0.f;
   const int n = D * D;
@@ -205,7 +210,21 @@ __global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restri
     if (G) G[idx] = g;
   }
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) atomicAdd(loss, s);
+  if (threadIdx.x == 0) bt_loss_partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void bt_loss_finish_kernel(int nblocks, float* __restrict__ loss) {
+  // lane l adds the partials l, l + 64, ... in order; the 64 lane sums are then added in lane order by lane 0
+  __shared__ float lanes[64];
+  float a = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 64) a += bt_loss_partials[b];
+  lanes[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int l = 0; l < 64; ++l) t += lanes[l];
+    *loss = t;
+  }
 }
 
 // ---- flat elementwise: AdamW (torch.optim.AdamW semantics, decoupled decay), EMA, scaled add
@@ -378,13 +397,9 @@ extern "C" int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const flo
 
 extern "C" int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream) {
   SA_CHECK_ARG(c && loss && D > 0, "sa_bt_loss_grad: bad args");
-  if (hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    sa_set_error("sa_bt_loss_grad: memset failed");
-    return 2;
-  }
-  int grid = (D * D + 255) / 256;
-  if (grid > 256) grid = 256;
-  hipLaunchKernelGGL(bt_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c, D, alpha, lambda, hsic, loss, G);
+  int grid = (int)(((int64_t)D * D + 255) / 256 < 256 ? ((int64_t)D * D + 255) / 256 : 256);
+  hipLaunchKernelGGL(bt_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c, D, alpha, lambda, hsic, G);
+  hipLaunchKernelGGL(bt_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, loss);
   SA_LAUNCH_CHECK("sa_bt_loss_grad");
   return 0;
 }

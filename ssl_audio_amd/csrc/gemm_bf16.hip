@@ -908,7 +908,8 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 }
 
 // column sums: block handles 64 columns x a slab of rows; 256 threads = 4 row-phases x 64 columns
-__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out, int rows_per_block) {
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out, int rows_per_block,
+                                   float* __restrict__ ws) {
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int ph = threadIdx.x >> 6;
@@ -919,13 +920,18 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int
     for (int r = r0 + ph; r < r1; r += 4) s += bf2f(x[(int64_t)r * ld + col]);
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
-  if (ph == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ph == 0 && col < N) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (ws) ws[(int64_t)blockIdx.y * N + col] = t;          // ordered form: row-slab partials, summed in slab order by colsum_ws_reduce_kernel
+    else atomicAdd(out + col, t);
+  }
 }
 
 // vectorised column sums: a block covers 256 columns (32 lanes x 8 bf16 = 512 contiguous bytes per row) x 8 row lanes,
-// so every load is a full-line 16-byte access; partial sums meet in LDS and leave as one atomic per column per block.
+// so every load is a full-line 16-byte access; partial sums meet in LDS and leave as one atomic per column per block -- or, with a
+// workspace, as one plain store per column per block (ws[row slab][N]; a second launch adds the slabs in order: bit-reproducible).
 __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, float* __restrict__ ws) {
   __shared__ float red[8][256 + 8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = blockIdx.x * 256 + tx * 8;
@@ -956,7 +962,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-    atomicAdd(out + c, s);
+    if (ws) ws[(int64_t)blockIdx.y * N + c] = s;
+    else atomicAdd(out + c, s);
   }
 }
 
@@ -964,7 +971,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
 
 namespace {
 // out[n] += sum over the rows of ws[rows][N]; 16 waves split the rows, lanes are columns
-__global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out,
+                                                                int assign = 0) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
@@ -987,7 +995,7 @@ __global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __r
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += red[w][lane];
-    out[col] += t;
+    out[col] = assign ? t : out[col] + t;
   }
 }
 
@@ -1045,7 +1053,7 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
     SA_LAUNCH_CHECK("sa_gemm_bf16(split-K reduce)");
   }
   if (rc != 0 || !a->colsum_out) return rc;
-  hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3(a->N / 64), dim3(1024), 0, stream, a->colsum_ws, (a->M + 63) / 64, a->N, a->colsum_out);
+  hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3(a->N / 64), dim3(1024), 0, stream, a->colsum_ws, (a->M + 63) / 64, a->N, a->colsum_out, 0);
   SA_LAUNCH_CHECK("sa_gemm_bf16(colsum reduce)");
   return 0;
 }
@@ -1253,33 +1261,48 @@ extern "C" int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void*
   return 0;
 }
 
-extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream) {
+extern "C" int64_t sa_colsum_workspace_bytes(int32_t M, int32_t N) {
+  // at most 1024 row slabs of >= 64 rows (what sa_colsum_bf16 cuts the rows into), N floats each
+  const int64_t slabs = (M + 63) / 64 < 1024 ? (M + 63) / 64 : 1024;
+  return (M > 0 && N > 0) ? slabs * N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, void* stream) {
   SA_CHECK_ARG(x && out && M > 0 && N > 0, "sa_colsum_bf16: bad args");
-  if (!accumulate) {
+  // ws (sa_colsum_workspace_bytes): every block stores its row slab's partial sums and a second launch adds the slabs in slab order
+  // -- bit-reproducible, and no float atomic anywhere; ws == NULL: one float atomic per column per block (order-dependent rounding)
+  if (!accumulate && !ws) {
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream) != hipSuccess) {
       sa_set_error("sa_colsum_bf16: memset failed");
       return 2;
     }
   }
+  int gy;
   if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0) {
     const int gx = (N + 255) / 256;
-    // two blocks per CU: every block ends with one atomic per column, and those -- not the 98 MB read -- set the time beyond that
-    // (measured on [63744, 768]: 512 blocks 18 us, 1024: 20, 2048: 24, 4096: 30)
-    int gy = (512 + gx - 1) / gx;
+    // atomic form: two blocks per CU -- every block ends with one atomic per column, and those, not the 98 MB read, set the time beyond
+    // that (measured on [63744, 768]: 512 blocks 18 us, 1024: 20, 2048: 24, 4096: 30); the workspace form ends in plain stores
+    gy = ((ws ? 1024 : 512) + gx - 1) / gx;
     const int max_gy = (M + 63) / 64;
     if (gy > max_gy) gy = max_gy;
+    if (gy > 1024) gy = 1024;
     const int rows_per_block = (((M + gy - 1) / gy) + 7) / 8 * 8;
     gy = (M + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block);
-    SA_LAUNCH_CHECK("sa_colsum_bf16");
-    return 0;
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block, ws);
+  } else {
+    const int gx = (N + 63) / 64;
+    gy = (2048 + gx - 1) / gx;
+    const int max_gy = (M + 63) / 64;
+    if (gy > max_gy) gy = max_gy;
+    if (gy > 1024) gy = 1024;
+    const int rows_per_block = (M + gy - 1) / gy;
+    gy = (M + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block, ws);
   }
-  const int gx = (N + 63) / 64;
-  int gy = (2048 + gx - 1) / gx;
-  const int max_gy = (M + 63) / 64;
-  if (gy > max_gy) gy = max_gy;
-  const int rows_per_block = (M + gy - 1) / gy;
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block);
   SA_LAUNCH_CHECK("sa_colsum_bf16");
+  if (ws) {
+    hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, gy, N, out, accumulate ? 0 : 1);
+    SA_LAUNCH_CHECK("sa_colsum_bf16(reduce)");
+  }
   return 0;
 }

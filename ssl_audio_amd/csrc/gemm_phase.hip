@@ -346,7 +346,10 @@ int launch256_phase_one(const GemmParams& p, hipStream_t stream, int slots) {
   const dim3 grid(nunits < budget_slots(slots) ? nunits : budget_slots(slots));
   GemmParams q = p;
   const int ksteps_all = (p.K + BK - 1) / BK;
-  const int min_nk = SPLIT ? ksteps_all / p.split_k : ksteps_all;                 // (the shortest K slice)
+  // the shortest K slice: slices are chunk = ceil(ksteps / split) K-tiles long, the LAST one holds what is left (the floor
+  // overstated it, e.g. 100 K-tiles in 13 slices: floor 7, last slice 4 -- the cursor then reads the next ticket before it is drawn)
+  const int chunk_nk = (ksteps_all + p.split_k - 1) / p.split_k;
+  const int min_nk = SPLIT ? ksteps_all - (p.split_k - 1) * chunk_nk : ksteps_all;
   q.tile_counter = (min_nk >= 6 && nunits > (int)grid.x) ? sagemm::next_tile_counter(stream) : nullptr;
   hipLaunchKernelGGL((gemm256_phase_kernel<A_KM, B_KM, SPLIT, EPI>), grid, dim3(512), PH_LDS, stream, q);
   SA_LAUNCH_CHECK("sa_gemm_bf16(256 phased)");

@@ -15,13 +15,23 @@ __global__ void fill_cls_kernel(float* __restrict__ x, int S, int64_t seq_stride
   }
 }
 
-// dcls[j] += sum_s dx[s][0][j]
-__global__ void cls_grad_kernel(const float* __restrict__ dx, int S, int64_t seq_stride, int d, float* __restrict__ dcls) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d) return;
+// dcls[j] += sum_s dx[s][0][j].  One 1024-thread block per 64 columns: wave w adds the rows s = w, w + 16, ... and the sixteen wave
+// sums meet in LDS in wave order -- a fixed summation order and a single writer per column (no float atomics: bit-reproducible).
+__global__ __launch_bounds__(1024) void cls_grad_kernel(const float* __restrict__ dx, int S, int64_t seq_stride, int d, float* __restrict__ dcls) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   float a = 0.f;
-  for (int s = blockIdx.y; s < S; s += gridDim.y) a += dx[(int64_t)s * seq_stride + j];
-  atomicAdd(dcls + j, a);
+  if (j < d)
+    for (int s = wave; s < S; s += 16) a += dx[(int64_t)s * seq_stride + j];
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && j < d) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    dcls[j] += t;
+  }
 }
 
 // dst[s][dst_row0 + k][:] = src[s][src_row0 + idx[s][k]][:]  (k < n_idx); fp32 rows of width d (multiple of 4)
@@ -250,8 +260,7 @@ extern "C" int sa_fill_cls(float* x, int32_t S, int64_t seq_stride, int32_t d, c
 
 extern "C" int sa_cls_grad(const float* dx, int32_t S, int64_t seq_stride, int32_t d, float* dcls, void* stream) {
   SA_CHECK_ARG(dx && dcls && S > 0 && d > 0, "sa_cls_grad: bad args");
-  int gy = S < 64 ? S : 64;
-  hipLaunchKernelGGL(cls_grad_kernel, dim3((d + 255) / 256, gy), dim3(256), 0, (hipStream_t)stream, dx, S, seq_stride, d, dcls);
+  hipLaunchKernelGGL(cls_grad_kernel, dim3((d + 63) / 64), dim3(1024), 0, (hipStream_t)stream, dx, S, seq_stride, d, dcls);
   SA_LAUNCH_CHECK("sa_cls_grad");
   return 0;
 }

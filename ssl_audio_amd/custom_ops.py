@@ -56,7 +56,8 @@ SCHEMAS = {
     "ema_update_gated": ("sa_ema_update_gated", "(Tensor(a!) target, Tensor online, float beta, Tensor? skip_flag) -> ()"),
     "axpy": ("sa_axpy_f32", "(Tensor(a!) y, Tensor x, float a=1.0) -> ()"),
     "count_nonfinite": ("sa_count_nonfinite", "(Tensor x, Tensor(a!) flag) -> ()"),
-    "logmel_fwd": ("sa_logmel_fwd", "(Tensor wave, Tensor tables, Tensor(a!) out, int T_out, int start, float mean, float std, int hop) -> ()"),
+    "logmel_fwd": ("sa_logmel_fwd", "(Tensor wave, Tensor window, Tensor twiddle, Tensor mel_weights, Tensor mel_lo, Tensor mel_len, Tensor(a!) out, int T_out, "
+                   "int start, float mean, float std, int hop) -> ()"),
     "augment_views": ("sa_augment_views", "(Tensor lms, int clip_stride, Tensor src_slot, Tensor mix_slot, Tensor params, Tensor(a!) out, int F_in, int T_in, "
                       "Tensor(b!) canvas, float max_w_ratio, bool do_fade) -> ()"),
     "normalize_batch": ("sa_normalize_batch", "(Tensor x, Tensor(a!) y, float shift, Tensor(b!) workspace, float eps, float stat_div=1.0) -> ()"),
@@ -103,6 +104,16 @@ SCHEMAS = {
 _LIB = None
 
 
+def _logmel_fwd(wave, window, twiddle, mel_weights, mel_lo, mel_len, out, T_out, start, mean, std, hop):
+    """The dispatcher carries tensors, `ops.logmel_fwd` takes frontend.build_tables' dict: the five tables travel as five arguments
+    (the registered schema had one `Tensor tables` and could not be called)."""
+    ops.logmel_fwd(wave, {"window": window, "twiddle": twiddle, "mel_weights": mel_weights, "mel_lo": mel_lo, "mel_len": mel_len},
+                   out, T_out, start, mean, std, hop)
+
+
+_ADAPTERS = {"logmel_fwd": _logmel_fwd}       # operators whose dispatcher signature differs from the `ops` function's
+
+
 def _arg_names(schema):
     """Argument names of a schema string, with the keyword-only ones (after `*`) flagged."""
     inner = schema[schema.index("(") + 1:schema.rindex(") ->")]
@@ -133,7 +144,7 @@ def register():
     lib = torch.library.Library(NAMESPACE, "DEF")
     for name, (_symbol, schema) in SCHEMAS.items():
         lib.define(name + schema)
-        fn = getattr(ops, name)
+        fn = _ADAPTERS.get(name) or getattr(ops, name)
         names = _arg_names(schema)
 
         def impl(*args, _fn=fn, _names=names, **kwargs):

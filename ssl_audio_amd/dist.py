@@ -110,8 +110,13 @@ class GradSumParallel(nn.Module):
     callback queued on the autograd engine for the end of the pass reduces what is left (buckets that stayed incomplete because some
     parameter received no gradient) and joins the stream.  Static buckets make the collective sequence identical on every rank
     whatever order the hooks fire in.  One backward per optimiser step, like DDP without no_sync(): a second backward before the
-    step would sum the first one's (already reduced) gradients again and raises instead.
+    step would all-reduce the first one's (already summed) gradients again (x W) and raises instead.  "Before the step" is tracked
+    per wrapper: the end of a reduced backward marks the bucket views as holding rank-summed gradients; the mark is dropped by any
+    `torch.optim.Optimizer.step()` (a global post-step hook), by `grads_consumed()` for hand-written update loops, and per parameter
+    when its `.grad` was replaced (`zero_grad(set_to_none=True)`, the default).
     """
+
+    _live = None                                    # weak set of wrappers the global optimiser-step hook clears
 
     def __init__(self, module, bucket_bytes=64 << 20):
         super().__init__()
@@ -136,8 +141,20 @@ class GradSumParallel(nn.Module):
                 off += (p.numel() + 3) // 4 * 4     # 16-byte aligned slices
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self._flat = [None] * len(self._buckets)    # allocated on the first backward (the parameters' device is final by then)
+        self._holds_sum = False                     # bucket views hold rank-summed gradients no optimiser step has consumed yet
         self._reset()
+        if GradSumParallel._live is None:
+            import weakref
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            GradSumParallel._live = weakref.WeakSet()
+            register_optimizer_step_post_hook(lambda *a, **k: [w.grads_consumed() for w in list(GradSumParallel._live)] and None)
+        GradSumParallel._live.add(self)
         reserve_cus_for_collectives()
+
+    def grads_consumed(self):
+        """The summed gradients have been applied (called by the global optimiser-step hook; call it yourself after a hand-written
+        parameter update that is not a `torch.optim.Optimizer`)."""
+        self._holds_sum = False
 
     def _reset(self):
         self._arrived = [0] * len(self._buckets)
@@ -176,6 +193,12 @@ class GradSumParallel(nn.Module):
         b, off = self._where[id(p)]
         flat = self._bucket_buffer(b)
         view = flat[off:off + p.numel()].view_as(p)
+        if self._holds_sum and p.grad.data_ptr() == view.data_ptr():
+            # autograd accumulated this pass's local gradient INTO the previous pass's rank-summed one: reducing the bucket again
+            # would count the old sum W times
+            raise RuntimeError("GradSumParallel: second backward before the optimiser step -- the gradients of the previous pass are "
+                               "already summed over ranks and would be all-reduced again (gradient accumulation is not supported: "
+                               "one backward per step; after a hand-written update call .grads_consumed())")
         if p.grad.data_ptr() != view.data_ptr():    # autograd allocated this gradient: move it into the bucket, keep the view
             view.copy_(p.grad)
             p.grad = view
@@ -210,5 +233,6 @@ class GradSumParallel(nn.Module):
                 work.wait()
             if self._stream is not None:
                 torch.cuda.current_stream().wait_stream(self._stream)
+            self._holds_sum = True
         finally:
             self._reset()

@@ -205,7 +205,9 @@ def cast_bf16(src, dst=None):
 
 def colsum_bf16(x, out, accumulate=False):
     M, N, ld = _rows(_req(x, BF16, "x"), "x")
-    check(lib().sa_colsum_bf16(_p(x), ld, M, N, _p(_req(out, F32, "out")), int(accumulate), _stream()), "sa_colsum_bf16")
+    # SA_DETERMINISTIC (default on): slab partials through a workspace, added in slab order -- no float atomics, bit-reproducible
+    ws = _p(_workspace(lib().sa_colsum_workspace_bytes(M, N), x.device, "colsum")) if DETERMINISTIC_WGRAD else None
+    check(lib().sa_colsum_bf16(_p(x), ld, M, N, _p(_req(out, F32, "out")), int(accumulate), ws, _stream()), "sa_colsum_bf16")
     return out
 
 

@@ -336,7 +336,12 @@ class BarlowTwinsTrainer:
         self.augment = BatchedPairAugment(device, cfg.n_mels, cfg.crop_frames, cfg.crop_frames, cfg.mixup, cfg.RRC, cfg.RLF,
                                           cfg.mixup_ratio, virtual_crop_scale=tuple(cfg.virtual_crop_scale), seed=seed + 1000 * sdist.get_rank())
         self.post_norm = NormalizeBatch() if cfg.post_norm else None
-        self.lr, self.wd = cfg.lr, cfg.wd
+        if getattr(cfg, "local_crops_number", 0) > 0 or getattr(cfg, "Gnoise", False):
+            # (utils/transforms.py:38-47, main.py:86-119 with ncrops = L + 2): the batched device path produces two global views and no
+            # Gaussian-noise mix; the per-sample module path (transforms.AudioPairTransform + MultiCropWrapper + BarlowTwinsLoss) runs both
+            raise NotImplementedError("BarlowTwinsTrainer: local crops (--local_crops_number) and --Gnoise are not on the batched device path; "
+                                      "use transforms.AudioPairTransform with MultiCropWrapper / BarlowTwinsLoss(ncrops=L+2)")
+        self.wd = cfg.wd
         # What `optimizer.param_groups` is to the reference's loop: utils.adjust_learning_rate(args, trainer, loader, iteration) --
         # main.py:52's call with this object in the optimiser's place -- writes the step's learning rates here, in get_optimizer's group
         # order (encoder decayed / un-decayed, then the predictor's two groups); the fused AdamW launches read them.
@@ -352,6 +357,16 @@ class BarlowTwinsTrainer:
         self._nonfinite = torch.zeros(1, dtype=torch.int32, device=device)
         self.finite_check_every = 100
         self._steps = 0
+
+    @property
+    def lr(self):
+        """The encoder's decayed-group learning rate, i.e. what the AdamW launches use (`param_groups` is the single source)."""
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        for g in self.param_groups:
+            g["lr"] = value
 
     # ------------------------------------------------------------------ data path
     def make_views(self, batch):
@@ -422,6 +437,7 @@ class BarlowTwinsTrainer:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
             self._graph.replay()
+            self.last_loss = self._graph_loss.clone()      # (the static tensor is overwritten by the next replay: callers keep their own)
         else:
             self.last_loss = self._device_step(views, mask_ratio)
         self._steps += 1

@@ -132,6 +132,29 @@ def main():
     r5 = accd * auxd.cpu().double()
     assert float((runs[True][4].cpu().double() - r5).norm() / r5.norm()) < 4e-3
     assert float((runs[True][5].cpu().double() - r5.sum(0)).norm() / r5.sum(0).norm()) < 1e-4
+    # split-K weight gradient under dynamic hand-out with a RAGGED last K slice: 100 K-tiles in 13 slices of 8 leave a last
+    # slice of 4, shorter than the phased kernel's ticket look-ahead, so that kernel must fall back to static striding for this launch;
+    # 4 x 5 tiles x 13 slices = 260 units > 256 workgroups.  Atomic accumulation (no workspace) is the form SA_GEMM_WGRAD_PHASE=1 /
+    # SA_GEMM_WGRAD_RING=1 take; dynamic and static must agree to fp32 summation-order noise and be right against fp64.
+    Ts, Ns, Ks = 6400, 1024, 1280
+    dYs = bf(torch.randn(Ts, Ns, generator=g)).to(dev); Xs = bf(torch.randn(Ts, Ks, generator=g)).to(dev)
+    refs = dYs.cpu().double().T @ Xs.cpu().double()
+    det = ops.DETERMINISTIC_WGRAD
+    for deterministic in (True, False):
+        ops.DETERMINISTIC_WGRAD = deterministic
+        outs = []
+        for dyn in (False, True):
+            ops.set_dynamic_tiles(dyn)
+            o = torch.zeros(Ns, Ks, device=dev)
+            ops.gemm(dYs, Xs, a_kmajor=False, b_kmajor=False, out_f32=o, split_k=13, tile256=True)
+            torch.cuda.synchronize()
+            assert float((o.cpu().double() - refs).norm() / refs.norm()) < 1e-5, (deterministic, dyn)
+            outs.append(o)
+        if deterministic:
+            assert torch.equal(outs[0], outs[1]), "dynamic hand-out changed a slice-ordered weight gradient"
+        else:
+            assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * float(outs[0].abs().max())
+    ops.DETERMINISTIC_WGRAD = det
     torch.cuda.synchronize()
     print(f"ok tile={os.environ.get('SA_GEMM_TILE', 'default')} ring_wgrad={os.environ.get('SA_GEMM_WGRAD_RING', '0')} worst={worst:.2e} wgrad={ew:.2e}")
 

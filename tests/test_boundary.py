@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in syms if not hasattr(h, s)]
     assert not missing, missing
     h.sa_abi_version.restype = ctypes.c_int
-    assert h.sa_abi_version() == 4
+    assert h.sa_abi_version() == 5
     # every declared function has ctypes argument types (a missing entry would silently pass ints as 32-bit)
     assert [s for s in syms if s not in _lib._SIGNATURES and s != "sa_last_error"] == []
 
@@ -219,14 +219,15 @@ def test_custom_ops_cover_every_compute_entry_point():
     covered = {sym for sym, _ in custom_ops.SCHEMAS.values()}
     plain = {s for s in _lib.header_symbols() if s not in covered}
     assert plain == {"sa_abi_version", "sa_last_error", "sa_device_info", "sa_set_cu_budget", "sa_set_dynamic_tiles", "sa_bn_tall_workspace_bytes",
-                     "sa_gemm_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes"}, plain
+                     "sa_gemm_colsum_workspace_bytes", "sa_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes"}, plain
     assert covered <= set(_lib.header_symbols())
     for name, (sym, schema) in custom_ops.SCHEMAS.items():
         op = getattr(torch.ops.ssl_audio, name).default
         sch = op._schema
         assert any(a.alias_info is not None and a.alias_info.is_write for a in sch.arguments), name      # every operator writes an argument
         assert len(sch.returns) == 0, name
-        assert [a.name for a in sch.arguments] == list(inspect.signature(getattr(ops, name)).parameters), name
+        impl = custom_ops._ADAPTERS.get(name) or getattr(ops, name)       # (an adapter re-packs arguments the dispatcher cannot carry)
+        assert [a.name for a in sch.arguments] == list(inspect.signature(impl).parameters), name
         src = inspect.getsource(getattr(ops, name))
         assert f"lib().{sym}(" in src, (name, sym)                                                           # ... and reaches the symbol it names
     with pytest.raises(NotImplementedError):

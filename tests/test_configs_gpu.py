@@ -282,10 +282,13 @@ def test_full_size_properties(dev, name, model_type, frames, B, mode):
 
 @pytest.mark.parametrize("mode", ["bt", "byol"])
 def test_graph_replay_equals_eager(dev, mode):
-    """the device part of the step captured into ONE HIP graph (BarlowTwinsTrainer.enable_graph) and replayed takes the
-    same steps as the eager path: same losses and the same weights / Adam moments / EMA target after four steps, with the learning rate
-    CHANGING between steps (it reaches the captured AdamW launches through device memory) -- agreement to fp32 summation-order noise
-    (the bias-gradient column sums use atomics), far below one bf16 ulp of any weight."""
+    """the device part of the step captured into ONE HIP graph (BarlowTwinsTrainer.enable_graph) and replayed takes
+    the same steps as the eager path, and two eager runs take the same steps as each other -- BIT FOR BIT over five steps: losses,
+    gradients, weights, Adam moments, EMA target and predictor, with the learning rate CHANGING between steps (it reaches the captured
+    AdamW launches through device memory).  No kernel on this path sums floats in an order that depends on scheduling (SA_DETERMINISTIC,
+    the default: split-K slices, bias column sums, the CLS-token gradient and the loss scalar all add their partials in a fixed order),
+    so any difference here is a race, not rounding."""
+    assert ops.DETERMINISTIC_WGRAD, "run with SA_DETERMINISTIC unset or 1"
     cfg = hp.make_args(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128,
                        stop_gradient=(mode == "byol"), predictor=(mode == "byol"))
     g = torch.Generator().manual_seed(4)
@@ -293,45 +296,52 @@ def test_graph_replay_equals_eager(dev, mode):
     batches = [[(b + 0.3 * torch.randn(8, 1, 64, 96, generator=g)).to(dev), (b + 0.3 * torch.randn(8, 1, 64, 96, generator=g)).to(dev)] for b in base]
     lrs = [1e-4, 3e-4, 2e-4, 5e-5, 1e-4]
 
+    def flats(tr):
+        out = {"online": tr.flat}
+        if mode == "byol":
+            out["target"], out["pred"] = tr.flat_target, tr.flat_pred
+        return out
+
     def run(graph):
         tr = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
-        losses = []
+        losses, trace = [], []
         for i, v in enumerate(batches):
             for grp in tr.param_groups:
                 grp["lr"] = lrs[i]
             losses.append(float(tr.step_views(v)))
+            snap = {}
+            for fname, fl in flats(tr).items():
+                for t in ("grads", "params", "m", "v"):
+                    if getattr(fl, t, None) is not None:
+                        snap[f"{fname}.{t}"] = getattr(fl, t).clone()
+            trace.append(snap)
             if i == 0 and graph:
                 tr.enable_graph()
         torch.cuda.synchronize()
         assert (tr._graph is not None) == graph
-        return tr, losses
+        return tr, losses, trace
 
-    a, la = run(False)
-    a2, la2 = run(False)
-    b, lb = run(True)
+    def first_difference(ta, tb, what):
+        """First step / buffer / parameter at which two runs differ (the failure message names the tensor to look at)."""
+        for i, (sa, sb) in enumerate(zip(ta, tb)):
+            for k in sa:                                       # insertion order: grads before params before moments
+                if not torch.equal(sa[k], sb[k]):
+                    d = (sa[k] - sb[k]).abs()
+                    idx = int(d.argmax())
+                    return f"{what}: step {i}, buffer {k}, first/worst element {idx}: {float(sa[k].view(-1)[idx])!r} vs {float(sb[k].view(-1)[idx])!r} (max |diff| {float(d.max()):.3e}, {int((d > 0).sum())} of {d.numel()} differ)"
+        return None
+
+    a, la, ta = run(False)
+    a2, la2, ta2 = run(False)
+    b, lb, tb = run(True)
     print(mode, "eager losses", la, "eager again", la2, "graph losses", lb)
-    # Two EAGER runs already differ by fp32 summation-order noise (atomic bias-gradient sums), and at batch 8 one bf16 rounding that
-    # this noise tips the other way can grow to 1e-3 of a loss within a step or two (scripts/diag_byol_repro.py: the gradients of two
-    # identical eager trainers agree to 2e-8 until such a flip, then to 5e-4).  The comparison therefore covers the steps over which
-    # eager reproduces eager; a stale learning rate or bias correction inside the graph would show from its first replayed step on.
-    same = lambda x, y: abs(x - y) <= 2e-5 * abs(x)
-    stable = next((i for i, (x, y) in enumerate(zip(la, la2)) if not same(x, y)), len(la))
-    assert stable >= 3, (la, la2)
-    for i, (x, y) in enumerate(zip(la, lb)):         # the learning rate changes 1e-4 -> 3e-4 -> 2e-4 over the strictly compared steps
-        assert same(x, y) if i < 3 else abs(x - y) <= 1e-2 * abs(x), (la, lb)
     assert a.flat.step_count == b.flat.step_count == 5
-    if stable == len(la) and all(same(x, y) for x, y in zip(la, lb)):
-        for name in ("params", "m", "v"):
-            ta, tb = getattr(a.flat, name), getattr(b.flat, name)
-            assert float((ta - tb).abs().max()) <= 2e-3 * float(ta.abs().max()) and float((ta - tb).norm() / ta.norm()) < 1e-3, name
-        # the moved-by-lr structure: a wrong (stale) learning rate or bias correction inside the graph would shift every weight by O(lr)
-        moved = float((a.flat.params - b.flat.params).abs().max())
-        assert moved <= 0.3 * min(lrs), moved
-        if mode == "byol":
-            assert float((a.flat_target.params - b.flat_target.params).abs().max()) <= 0.3 * min(lrs)
-            assert float((a.flat_pred.params - b.flat_pred.params).abs().max()) <= 0.3 * min(lrs)
-    else:
-        print("run-to-run divergence after step", stable, "(eager vs eager): weight comparison skipped")
+    diff = first_difference(ta, ta2, "eager vs eager")
+    assert diff is None, diff
+    assert la == la2, (la, la2)
+    diff = first_difference(ta, tb, "eager vs graph replay")
+    assert diff is None, diff
+    assert la == lb, (la, lb)
     del a2
     # a non-finite loss leaves weights and moments untouched (device-side gate), and the host notices on its next look
     before = b.flat.params.clone(), b.flat.m.clone()

@@ -166,10 +166,41 @@ def _worker_body(rank, world, port, q):
     tot = sum(range(1, world + 1))
     ok_sync = (torch.all(flat2.grads[0:8] == tot) and torch.all(flat2.grads[80:88] == 10.0 * tot)
                and torch.all(flat2.grads[8:80] == 100.0 * tot) and torch.all(flat2.grads[88:] == 0)).item()
+    _double_backward_guard(rank, world)
     to_np = lambda d: {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in d.items()}   # no shared-memory tensors in the queue
     q.put((rank, bool(ok_bn), bool(ok_sync), None, to_np(res_exact), to_np(res_lit)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _double_backward_guard(rank, world):
+    """GradSumParallel: one backward per optimiser step.  A second backward that accumulates into the first
+    pass's rank-summed gradients raises; an optimiser step, grads_consumed() or zero_grad(set_to_none=True) re-arm it, and the
+    gradients after each legal pass are the SUM over ranks of that pass alone."""
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(6, 4)
+    net = sdist.GradSumParallel(lin, bucket_bytes=64)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.0)
+    x = torch.full((2, 6), float(rank + 1))
+    tot = float(sum(range(1, world + 1)))
+    expect_w = torch.full((4, 6), 2.0 * tot)                   # d(sum y)/dW = sum over rows of x, summed over ranks
+
+    net(x).sum().backward()
+    assert torch.equal(lin.weight.grad, expect_w)
+    with pytest.raises(RuntimeError, match="second backward"):
+        net(x).sum().backward()                                # accumulates into the summed gradient: refused
+    dist.barrier()                                             # (both ranks raised before any collective of the refused pass)
+    opt.step()                                                 # lr 0: consumes the gradients, weights unchanged
+    lin.weight.grad.zero_(); lin.bias.grad.zero_()             # zero_grad(set_to_none=False) keeps the bucket views
+    net(x).sum().backward()
+    assert torch.equal(lin.weight.grad, expect_w), lin.weight.grad
+    opt.zero_grad(set_to_none=True)                            # replaced gradients: legal without a step
+    net(x).sum().backward()
+    assert torch.equal(lin.weight.grad, expect_w)
+    net.grads_consumed()
+    lin.weight.grad.zero_(); lin.bias.grad.zero_()
+    net(x).sum().backward()
+    assert torch.equal(lin.weight.grad, expect_w)
 
 
 def _close(a, b, tol):

@@ -619,3 +619,17 @@ def test_custom_ops_reach_the_same_kernels(dev):
     ver = p2._version
     torch.ops.ssl_audio.adamw_step(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 0.05, 1)
     assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and p2._version > ver
+    # the frontend operator takes its five tables as five tensors (a `Tensor tables` schema could not be called)
+    from ssl_audio_amd import frontend
+    tb = frontend.build_tables(dev)
+    wave = 0.1 * torch.randn(3, 16000, device=dev, generator=g)
+    l1, l2 = torch.empty(3, 64, 96, device=dev), torch.full((3, 64, 96), float("nan"), device=dev)
+    ops.logmel_fwd(wave, tb, l1, 96, 2, -0.8, 4.6, 160)
+    torch.ops.ssl_audio.logmel_fwd(wave, tb["window"], tb["twiddle"], tb["mel_weights"], tb["mel_lo"], tb["mel_len"], l2, 96, 2, -0.8, 4.6, 160)
+    assert torch.equal(l1, l2)
+    # column sums: the ordered (workspace) form is bit-reproducible and equals the direct route
+    y = torch.randn(5000, 768, device=dev, generator=g).to(BF16)
+    c1, c2, c3 = torch.empty(768, device=dev), torch.empty(768, device=dev), torch.empty(768, device=dev)
+    ops.colsum_bf16(y, c1); ops.colsum_bf16(y, c2); torch.ops.ssl_audio.colsum_bf16(y, c3)
+    assert torch.equal(c1, c2) and torch.equal(c1, c3)
+    assert float((c1.double().cpu() - y.double().sum(0).cpu()).abs().max()) < 1e-2
