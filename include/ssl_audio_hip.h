@@ -194,11 +194,14 @@ int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32
  * (augmentations.py:40-55) and RandomLinearFader.forward (augmentations.py:69-74) with explicit parameters.
  * lms: base of the clip store (ring of normalised log-mels, clip k at lms + k*clip_stride, [F_in][T_in]);
  * src_slot[v]: clip of view v; mix_slot[v]: bank clip to mix in, or -1 (NULL = no mixing);
- * params [n_views][8] fp32 = (alpha, i, j, h, w, head, tail, 0); out [n_views][F_out][T_out].
- * max_w_ratio >= max crop width / (T_out - 1) bounds the LDS source tile. */
+ * params [n_views][8] fp32 = (alpha, i, j, h, w, head, tail, lambda); out [n_views][F_out][T_out].
+ * max_w_ratio >= max crop width / (T_out - 1) bounds the LDS source tile.
+ * noise (ABI v5, optional): standard-normal draws [n_views][F_in][T_in]; when given, MixGaussianNoise (augmentations.py:132-141,
+ * `--Gnoise`, utils/transforms.py:21-22) is applied to the mixed source pixel before the crop:
+ * log((1 - lambda) exp(v) + exp(lambda n) + eps), lambda = params[view][7]. */
 int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_slot, const int32_t* mix_slot, const float* params,
                      float* out, int32_t n_views, int32_t F_in, int32_t T_in, int32_t canvas_h, int32_t canvas_w, int32_t F_out,
-                     int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream);
+                     int32_t T_out, float max_w_ratio, int32_t do_fade, const float* noise, void* stream);
 /* NormalizeBatch (augmentations.py:229-232) over n contiguous floats; workspace2 = 2 doubles; shift ~ mean guess.
  * stat_div = 1 is NormalizeBatch and the HEAR scene normalisation (hear/sample/vit.py:97-100); stat_div = number of frames
  * reproduces hear/utils.py:36-53, which divides BOTH statistics by len(melspec) before (x - mean) / std (hear/sample/vit.py:203-205) */

@@ -115,7 +115,7 @@ class PairTransformOracle:
     def __init__(self, n_mels=64, crop_frames=96, local_crops_number=0, local_crops_size=(16, 16),
                  mixup=True, rrc=True, rlf=True, mixup_ratio=0.2, virtual_crop_scale=(1.0, 1.5),
                  global_crop_scale=(0.6, 1.5), local_crop_scale=(0.05, 0.6), n_memory=2048, seed=None,
-                 np_rng=None, py_rng=None):
+                 np_rng=None, py_rng=None, gnoise=False, gnoise_ratio=0.2, normal_fn=None):
         self.out_size = (n_mels, crop_frames)
         self.L = local_crops_number
         self.local_size = tuple(local_crops_size)
@@ -125,6 +125,9 @@ class PairTransformOracle:
         self.gscale, self.lscale = tuple(global_crop_scale), tuple(local_crop_scale)
         self.n = n_memory
         self.bank = []
+        # --Gnoise (utils/transforms.py:21-22): MixGaussianNoise(ratio) between mixup and the crop of the global views.  The reference
+        # draws its normals with torch.normal; here they come from `normal_fn(shape)` so a test can hand both sides the same draws
+        self.gnoise, self.gnoise_ratio, self.normal_fn = gnoise, gnoise_ratio, normal_fn
         self.np_rng = np_rng if np_rng is not None else np.random.RandomState(seed)
         self.py_rng = py_rng if py_rng is not None else _pyrandom.Random(seed)
         self.records = []
@@ -142,6 +145,10 @@ class PairTransformOracle:
             else:
                 rec["bank_index"] = -1
             self.bank = (self.bank + [x])[-self.n:]                     # :115 (stores the UN-mixed input)
+        if self.gnoise:
+            lambd = self.gnoise_ratio * self.np_rng.rand()              # :135
+            rec["lambd"] = lambd
+            y = mix_gaussian_noise(np.asarray(y, dtype=np.float32), lambd, self.normal_fn(x.shape)).astype(np.float64)
         if self.rrc:
             canvas = canvas_size(x.shape[-2:], self.vcs)
             p = draw_rrc_params(self.np_rng, self.py_rng, canvas, x.shape[-2:], self.gscale, self.gscale)

@@ -23,13 +23,13 @@ from . import ops
 EPS32 = 1.1920929e-07
 
 
-def _launch(store, clip_stride, src, mix, params, out, F_in, T_in, canvas, do_fade):
+def _launch(store, clip_stride, src, mix, params, out, F_in, T_in, canvas, do_fade, noise=None):
     dev = store.device
     p = torch.tensor(params, dtype=torch.float32).reshape(-1, 8).to(dev, non_blocking=True)
     s = torch.tensor(src, dtype=torch.int32).to(dev, non_blocking=True)
     m = torch.tensor(mix, dtype=torch.int32).to(dev, non_blocking=True) if mix is not None else None
     ratio = canvas[1] / max(out.shape[-1] - 1, 1)
-    ops.augment_views(store, clip_stride, s, m, p, out, F_in, T_in, canvas, ratio, do_fade)
+    ops.augment_views(store, clip_stride, s, m, p, out, F_in, T_in, canvas, ratio, do_fade, noise)
     return out
 
 
@@ -204,18 +204,33 @@ class BatchedPairAugment:
 
     The clip store is a device ring of normalised log-mels; `next_slots(B)` tells the caller (frontend) where to
     write the next batch so no copy is needed.  Event e = 2*clip + view appends clip e//2 to the virtual FIFO
-    (augmentations.py:115, un-mixed input, capped at n_memory entries) after mixing with entry randint(len)."""
+    (augmentations.py:115, un-mixed input, capped at n_memory entries) after mixing with entry randint(len).
+
+    `local_crops_number` = L > 0 adds the L local views of utils/transforms.py:38-47,54-55 (RandomResizeCrop of the UN-mixed clip to
+    `local_crops_size`, virtual crop scale (1, 1), scales (0.05, 0.6); a second launch), drawn per clip after its two global views --
+    the reference's RNG call order; `gnoise` inserts MixGaussianNoise (utils/transforms.py:21-22) between mixup and the crop of the
+    global views, inside the same launch: lambda = gnoise_ratio * np.random.rand() per view from the numpy stream, the normal
+    draws from a torch generator on the device (the reference draws them with torch.normal on the host: a different stream by
+    construction; `normal_override` feeds recorded draws for parity tests)."""
 
     def __init__(self, device, n_mels=64, frames=1001, out_frames=None, mixup=True, rrc=True, rlf=True, mixup_ratio=0.2,
-                 n_memory=2048, virtual_crop_scale=(1.0, 1.5), crop_scale=(0.6, 1.5), seed=None):
+                 n_memory=2048, virtual_crop_scale=(1.0, 1.5), crop_scale=(0.6, 1.5), seed=None, local_crops_number=0,
+                 local_crops_size=(16, 16), local_crop_scale=(0.05, 0.6), gnoise=False, gnoise_ratio=0.2):
         self.device = device
         self.F, self.T = n_mels, frames
         self.T_out = out_frames or frames
         self.mixup, self.rrc, self.rlf = mixup, rrc, rlf
         self.ratio, self.n = mixup_ratio, n_memory
         self.vcs, self.scale = tuple(virtual_crop_scale), tuple(crop_scale)
+        self.L, self.local_size, self.local_scale = int(local_crops_number), tuple(local_crops_size), tuple(local_crop_scale)
+        self.gnoise, self.gnoise_ratio = bool(gnoise), gnoise_ratio
         self.np_rng = np.random.RandomState(seed) if seed is not None else np.random
         self.py_rng = random.Random(seed) if seed is not None else random
+        self.torch_gen = None
+        if self.gnoise and seed is not None:
+            self.torch_gen = torch.Generator(device=device)
+            self.torch_gen.manual_seed(seed)
+        self.normal_override = None   # [2B, F, T] standard-normal draws for the next call (parity tests), ordered like the views
         self.events = 0          # views processed so far == FIFO appends so far
         self.clips = 0           # clips processed so far
         self.store = None
@@ -240,16 +255,18 @@ class BatchedPairAugment:
 
     def draw(self, B):
         """Host-side sampling in the reference's RNG call order; returns src, mix, params lists ordered
-        [view0 of all clips..., view1 of all clips...] while DRAWING in event order clip0v0, clip0v1, clip1v0, ..."""
+        [view0 of all clips..., view1 of all clips...] while DRAWING in event order clip0v0, clip0v1, [clip0 locals,] clip1v0, ...
+        (`self.local_draw` = (src, params) of the L * B local views, ordered [local0 of all clips..., local1 ...])."""
         canvas = [int(s * c) for s, c in zip((self.F, self.T), self.vcs)] if self.rrc else [self.F, self.T]
         src = [0] * (2 * B)
         mix = [-1] * (2 * B)
         par = [None] * (2 * B)
+        lsrc, lpar = [0] * (self.L * B), [None] * (self.L * B)
         self.records = []
         for b in range(B):
             clip = self.clips + b
             for v in range(2):
-                alpha, k = 0.0, -1
+                alpha, k, lam = 0.0, -1, 0.0
                 if self.mixup:
                     alpha = self.ratio * self.np_rng.random_sample()
                     c = min(self.events, self.n)
@@ -258,24 +275,46 @@ class BatchedPairAugment:
                         g = self.events - c + k                       # global append index of FIFO entry k
                         mix[v * B + b] = (g // 2) % self.capacity
                     self.events += 1
+                if self.gnoise:
+                    lam = self.gnoise_ratio * self.np_rng.rand()      # augmentations.py:135
                 if self.rrc:
                     i, j, h, w = draw_rrc_params(canvas, (self.F, self.T), self.scale, self.scale, self.np_rng, self.py_rng)
                 else:
                     i, j, h, w = 0, 0, self.F, self.T
                 head, tail = (1.0 * ((2.0 * self.np_rng.rand(2)) - 1.0)) if self.rlf else (0.0, 0.0)
                 src[v * B + b] = clip % self.capacity
-                par[v * B + b] = [alpha if k >= 0 else 0.0, i, j, h, w, head, tail, 0.0]
+                par[v * B + b] = [alpha if k >= 0 else 0.0, i, j, h, w, head, tail, lam]
                 self.records.append({"clip": clip, "view": v, "alpha": alpha, "bank_index": k, "rrc": (i, j, h, w),
-                                     "head_tail": (head, tail)})
+                                     "head_tail": (head, tail), "lambd": lam})
+            for l in range(self.L):                                   # utils/transforms.py:54-55: the un-mixed clip, no fade
+                i, j, h, w = draw_rrc_params((self.F, self.T), (self.F, self.T), self.local_scale, self.local_scale, self.np_rng, self.py_rng)
+                lsrc[l * B + b] = clip % self.capacity
+                lpar[l * B + b] = [0.0, i, j, h, w, 0.0, 0.0, 0.0]
+                self.records.append({"clip": clip, "local": l, "rrc": (i, j, h, w)})
+        self.local_draw = (lsrc, lpar)
         return src, mix, par, canvas
 
     def __call__(self, B, out=None):
-        """Augment the batch previously written into `next_slots(B)`; returns views [2, B, 1, F, T_out]."""
+        """Augment the batch previously written into `next_slots(B)`; returns views [2, B, 1, F, T_out] -- or, with local crops, the
+        crop list the reference's transform yields per clip, batched: [view1, view2, local_1 .. local_L], each [B, 1, h, w]."""
         self._ensure_store(B)
         src, mix, par, canvas = self.draw(B)
         if out is None:
             out = torch.empty(2, B, 1, self.F, self.T_out, device=self.device)
+        noise = None
+        if self.gnoise:
+            noise = self.normal_override
+            self.normal_override = None
+            if noise is None:
+                noise = torch.randn(2 * B, self.F, self.T, device=self.device, generator=self.torch_gen)
         _launch(self.store, self.F * self.T, src, mix if self.mixup else None, par, out.view(2 * B, 1, self.F, self.T_out), self.F, self.T,
-                canvas, self.rlf)
+                canvas, self.rlf, noise)
+        crops = out
+        if self.L:
+            lh, lw = self.local_size
+            loc = torch.empty(self.L, B, 1, lh, lw, device=self.device)
+            _launch(self.store, self.F * self.T, self.local_draw[0], None, self.local_draw[1], loc.view(self.L * B, 1, lh, lw), self.F, self.T,
+                    (self.F, self.T), False)
+            crops = [out[0], out[1]] + [loc[l] for l in range(self.L)]
         self.clips += B
-        return out
+        return crops

@@ -24,7 +24,7 @@ struct ViewParams {  // mirrored by ssl_audio_amd/augmentations.py (8 x float32 
   float alpha;       // mixup weight of the bank entry (0.2 * U[0,1)); ignored when mix_slot < 0
   float i, j, h, w;  // crop rectangle on the virtual canvas (integers stored as float)
   float head, tail;  // fader end points
-  float pad;
+  float lambd;       // MixGaussianNoise weight (ratio * U[0,1)); used only when the launch carries a noise tensor
 };
 
 __device__ __forceinline__ void cubic_w(float t, float w[4]) {
@@ -38,7 +38,7 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
 __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ lms, int64_t clip_stride, const int* __restrict__ src_slot,
                                                       const int* __restrict__ mix_slot, const ViewParams* __restrict__ params,
                                                       float* __restrict__ out, int F_in, int T_in, int canvas_h, int canvas_w, int F_out,
-                                                      int T_out, int TT, int do_fade) {
+                                                      int T_out, int TT, int do_fade, const float* __restrict__ noise) {
   __shared__ float tile[LDS_H * LDS_W];
   const int view = blockIdx.y;
   const int t0 = blockIdx.x * TT;
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   const int ms = mix_slot ? mix_slot[view] : -1;
   const float* z = ms >= 0 ? lms + (int64_t)ms * clip_stride : nullptr;
   const float wa = 1.f - pr.alpha, wb = pr.alpha;  // log_mixup_exp(x, z, 1 - alpha): weight of x is 1 - alpha
+  // MixGaussianNoise between mixup and the crop (utils/transforms.py:21-22, augmentations.py:132-141): standard-normal draws of this
+  // view's [F_in, T_in] grid, a function of the SOURCE pixel, so the halo columns two slabs share get the same noise
+  const float* nz = noise ? noise + (int64_t)view * F_in * T_in : nullptr;
   // paste offsets of the input on the canvas (augmentations.py:47)
   const int px = (canvas_w - T_in) / 2, py = (canvas_h - F_in) / 2;
 
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
       if (row_in && cc >= 0 && cc < T_in) {
         v = x[(int64_t)r * T_in + cc];
         if (z) v = logf(wa * expf(v) + wb * expf(z[(int64_t)r * T_in + cc]) + kEps32);
+        if (nz) v = logf((1.f - pr.lambd) * expf(v) + expf(pr.lambd * nz[(int64_t)r * T_in + cc]) + kEps32);
       }
       tile[yy * LDS_W + xx] = v;
     }
@@ -189,7 +193,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
 
 extern "C" int sa_augment_views(const float* lms, int64_t clip_stride, const int32_t* src_slot, const int32_t* mix_slot, const float* params,
                                 float* out, int32_t n_views, int32_t F_in, int32_t T_in, int32_t canvas_h, int32_t canvas_w, int32_t F_out,
-                                int32_t T_out, float max_w_ratio, int32_t do_fade, void* stream) {
+                                int32_t T_out, float max_w_ratio, int32_t do_fade, const float* noise, void* stream) {
   SA_CHECK_ARG(lms && src_slot && params && out && n_views > 0, "sa_augment_views: bad args");
   SA_CHECK_ARG(canvas_h <= LDS_H, "sa_augment_views: canvas height %d exceeds the %d-row LDS tile", canvas_h, LDS_H);
   SA_CHECK_ARG(F_out > 0 && T_out > 0 && F_in > 0 && T_in > 0 && max_w_ratio > 0.f, "sa_augment_views: bad sizes");
@@ -199,7 +203,7 @@ extern "C" int sa_augment_views(const float* lms, int64_t clip_stride, const int
   SA_CHECK_ARG(TT >= 1, "sa_augment_views: crop/out width ratio %f too large", max_w_ratio);
   dim3 grid((T_out + TT - 1) / TT, n_views);
   hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, (hipStream_t)stream, lms, clip_stride, src_slot, mix_slot,
-                     reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade);
+                     reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade, noise);
   SA_LAUNCH_CHECK("sa_augment_views");
   return 0;
 }

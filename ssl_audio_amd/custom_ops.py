@@ -58,8 +58,8 @@ SCHEMAS = {
     "count_nonfinite": ("sa_count_nonfinite", "(Tensor x, Tensor(a!) flag) -> ()"),
     "logmel_fwd": ("sa_logmel_fwd", "(Tensor wave, Tensor window, Tensor twiddle, Tensor mel_weights, Tensor mel_lo, Tensor mel_len, Tensor(a!) out, int T_out, "
                    "int start, float mean, float std, int hop) -> ()"),
-    "augment_views": ("sa_augment_views", "(Tensor lms, int clip_stride, Tensor src_slot, Tensor mix_slot, Tensor params, Tensor(a!) out, int F_in, int T_in, "
-                      "Tensor(b!) canvas, float max_w_ratio, bool do_fade) -> ()"),
+    "augment_views": ("sa_augment_views", "(Tensor lms, int clip_stride, Tensor src_slot, Tensor? mix_slot, Tensor params, Tensor(a!) out, int F_in, int T_in, "
+                      "int[] canvas, float max_w_ratio, bool do_fade, Tensor? noise=None) -> ()"),
     "normalize_batch": ("sa_normalize_batch", "(Tensor x, Tensor(a!) y, float shift, Tensor(b!) workspace, float eps, float stat_div=1.0) -> ()"),
     "patchify_bf16": ("sa_patchify_bf16", "(Tensor img, Tensor(a!) out, int ph, int pw) -> ()"),
     "fill_cls": ("sa_fill_cls", "(Tensor(a!) x, int S, int seq_stride, int d, Tensor cls, Tensor pos0) -> ()"),

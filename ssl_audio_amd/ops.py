@@ -365,13 +365,15 @@ def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop):
            flops=float(B) * T_out * (5.0 * 1024 * 10 + 1024 + 3 * 513 + 4 * 513))
 
 
-def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in, canvas, max_w_ratio, do_fade):
+def augment_views(lms, clip_stride, src_slot, mix_slot, params, out, F_in, T_in, canvas, max_w_ratio, do_fade, noise=None):
     V, F_out, T_out = out.shape[0], out.shape[-2], out.shape[-1]
-    # algorithmic bytes per view: the clip and its mixup partner read once, the view written once
-    _timed("augment_kernel", V * 4.0 * (2 * F_in * T_in + F_out * T_out), lambda: check(
+    if noise is not None and (_req(noise, F32, "noise").numel() != V * F_in * T_in or not noise.is_contiguous()):
+        raise ValueError(f"noise must be a contiguous [{V}, {F_in}, {T_in}] tensor of standard-normal draws")
+    # algorithmic bytes per view: the clip and its mixup partner (and the noise grid) read once, the view written once
+    _timed("augment_kernel", V * 4.0 * ((2 + (noise is not None)) * F_in * T_in + F_out * T_out), lambda: check(
         lib().sa_augment_views(_p(_req(lms, F32, "lms")), clip_stride, _p(src_slot), _p(mix_slot), _p(_req(params, F32, "params")),
                                _p(_req(out, F32, "out")), V, F_in, T_in, canvas[0], canvas[1], F_out, T_out, float(max_w_ratio),
-                               int(do_fade), _stream()), "sa_augment_views"))
+                               int(do_fade), _p(noise), _stream()), "sa_augment_views"))
 
 
 def normalize_batch(x, y, shift, workspace, eps, stat_div=1.0):

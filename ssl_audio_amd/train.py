@@ -230,13 +230,17 @@ class GradSync:
     """Gradient SUM all-reduce over ranks, bucketed per transformer block and overlapped with backward on a side
     HIP stream (collective site C3).  Buckets are contiguous ranges of FlatState.grads."""
 
-    def __init__(self, flat, bucket_bytes=64 << 20):
+    def __init__(self, flat, bucket_bytes=64 << 20, min_block_bytes=1 << 20):
         self.flat = flat
         self.world = sdist.get_world_size()
         self.active = sdist.collectives_active()
         self.stream = torch.cuda.Stream() if (self.active and flat.grads.is_cuda) else None
         self.pending = []
         self.bucket_bytes = bucket_bytes
+        # a block's un-decayed vectors (LayerNorm weights, biases: a few KB) are NOT worth a collective of their own -- twelve
+        # latency-bound all-reduces per step, each holding CUs next to the backward's GEMMs: runs below this size are left to finish(),
+        # where the whole un-decayed region (contiguous in the flat buffer) goes out as one range
+        self.min_block_bytes = min_block_bytes
         self._ready_ranges = []
 
     def block_done(self, params):
@@ -257,15 +261,20 @@ class GradSync:
         # contiguous run on its own -- a single min..max range would sweep up other layers' unfinished gradients
         spans.sort()
         run = None
+        runs = []
         for a, b in spans:
             if run is not None and a <= run[1]:
                 run = (run[0], max(run[1], b))
             else:
                 if run is not None:
-                    self._launch(run[0], min(run[1], self.flat.n_train))
+                    runs.append(run)
                 run = (a, b)
         if run is not None:
-            self._launch(run[0], min(run[1], self.flat.n_train))
+            runs.append(run)
+        for lo, hi in runs:
+            hi = min(hi, self.flat.n_train)
+            if (hi - lo) * 4 >= self.min_block_bytes:        # (small runs: reduced once, with their neighbours, by finish())
+                self._launch(lo, hi)
 
     def _launch(self, lo, hi):
         self._ready_ranges.append((lo, hi))
@@ -316,7 +325,12 @@ class BarlowTwinsTrainer:
         torch.manual_seed(seed)
         self.online = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
         self.flat = FlatState(list(self.online.named_parameters()), device)
-        self.criterion = BarlowTwinsLoss(cfg, ncrops=2).to(device)
+        # local crops (main.py:86-119 with ncrops = L + 2): the teacher sees global view 1, the student global view 2 and the L local views
+        self.L = int(getattr(cfg, "local_crops_number", 0) or 0)
+        if self.L and mode == "byol":
+            raise NotImplementedError("local crops with the two-network form: main_bt_byol.py:96-107 chunks the online output (2 crops) into "
+                                      "L + 2 pieces, which only lines up for L = 0")
+        self.criterion = BarlowTwinsLoss(cfg, ncrops=self.L + 2).to(device)
         sdist.reserve_cus_for_collectives()
         self.sync = self.flat.sync = GradSync(self.flat)
         self.predictor = self.target = self.flat_pred = self.flat_target = None
@@ -334,13 +348,9 @@ class BarlowTwinsTrainer:
         frames = self.frontend.n_frames(clip_samples) if from_waveform else cfg.crop_frames
         self.frames = frames
         self.augment = BatchedPairAugment(device, cfg.n_mels, cfg.crop_frames, cfg.crop_frames, cfg.mixup, cfg.RRC, cfg.RLF,
-                                          cfg.mixup_ratio, virtual_crop_scale=tuple(cfg.virtual_crop_scale), seed=seed + 1000 * sdist.get_rank())
+                                          cfg.mixup_ratio, virtual_crop_scale=tuple(cfg.virtual_crop_scale), seed=seed + 1000 * sdist.get_rank(),
+                                          local_crops_number=self.L, local_crops_size=tuple(cfg.local_crops_size), gnoise=bool(cfg.Gnoise))
         self.post_norm = NormalizeBatch() if cfg.post_norm else None
-        if getattr(cfg, "local_crops_number", 0) > 0 or getattr(cfg, "Gnoise", False):
-            # (utils/transforms.py:38-47, main.py:86-119 with ncrops = L + 2): the batched device path produces two global views and no
-            # Gaussian-noise mix; the per-sample module path (transforms.AudioPairTransform + MultiCropWrapper + BarlowTwinsLoss) runs both
-            raise NotImplementedError("BarlowTwinsTrainer: local crops (--local_crops_number) and --Gnoise are not on the batched device path; "
-                                      "use transforms.AudioPairTransform with MultiCropWrapper / BarlowTwinsLoss(ncrops=L+2)")
         self.wd = cfg.wd
         # What `optimizer.param_groups` is to the reference's loop: utils.adjust_learning_rate(args, trainer, loader, iteration) --
         # main.py:52's call with this object in the optimiser's place -- writes the step's learning rates here, in get_optimizer's group
@@ -381,10 +391,10 @@ class BarlowTwinsTrainer:
         if self._graph is not None and self.use_graph and self.post_norm is None and self._graph_views[0].shape[0] == B:
             out = self._graph_out()                          # the captured step's input buffers: the augmentation writes them in place
         views = self.augment(B, out=out)
-        v1, v2 = views[0], views[1]
+        crops = [views[i] for i in range(2 + self.L)]        # [view1, view2, local_1 .. local_L] (utils/transforms.py:49-56, batched)
         if self.post_norm is not None:
-            v1, v2 = self.post_norm(v1), self.post_norm(v2)
-        return [v1, v2]
+            crops = [self.post_norm(c) for c in crops]       # main.py:60-65: NormalizeBatch per crop
+        return crops
 
     def _graph_out(self):
         """[2, B, 1, F, T] tensor aliasing the two static view buffers when they are adjacent in memory (enable_graph allocates them so)."""
@@ -449,13 +459,21 @@ class BarlowTwinsTrainer:
         """Everything of a step that runs on the device, with no host-side state that changes from step to step (capturable)."""
         self.flat.zero_grad()
         engine.reset_pending_backward()
-        if self.mode == "bt":
+        if self.mode == "bt" and self.L == 0:
             z = self.online(views, ncrops=2)
             z1, z2 = z.chunk(2)
             loss = self.criterion.forward_loss(z1, z2)
+        elif self.mode == "bt":
+            # main.py:86-119: teacher = model(images[:1], ncrops=1), student = model(images[1:], ncrops=L+1).  The two global views share
+            # one encoder pass here (the encoder has no batch statistics and the head runs its BatchNorm per crop chunk, model.py:26-31,
+            # in the same order: view 1, view 2, locals), the 16-wide local crops go through as their own width group
+            z = self.online(views[:2], ncrops=2)
+            t, s1 = z.chunk(2)
+            sl = self.online(views[2:], ncrops=self.L)
+            loss = self.criterion(torch.cat([s1, sl]), t, ngcrops_each=1)
         elif self.mode == "mae":
             t, recon = self.online(views[:1], ncrops=1, mask_ratio=self.cfg.mask_ratio if mask_ratio is None else mask_ratio, masked_recon=True)
-            st = self.online(views[1:], ncrops=1)
+            st = self.online(views[1:], ncrops=1 + self.L)
             loss = self.criterion(st, t, ngcrops_each=1) + recon
         else:
             self.flat_pred.zero_grad()
@@ -493,6 +511,8 @@ class BarlowTwinsTrainer:
             raise RuntimeError("enable_graph(): run at least one eager step first (workspaces and weight copies are allocated lazily)")
         if self.mode == "mae":
             raise NotImplementedError("graph capture of mode 'mae' is not supported: its random masking draws from the host-visible generator")
+        if self.L:
+            raise NotImplementedError("graph capture with local crops is not supported (the static input buffers hold the two global views)")
         pair = torch.empty(2, self.B, 1, self.cfg.n_mels, self.cfg.crop_frames, device=self.device)
         if views is not None:
             pair[0].copy_(views[0]); pair[1].copy_(views[1])

@@ -280,6 +280,40 @@ def test_full_size_properties(dev, name, model_type, frames, B, mode):
     torch.cuda.empty_cache()
 
 
+def test_trainer_local_crops_step_vs_oracle(dev):
+    """BarlowTwinsTrainer(mode='bt') with cfg.local_crops_number = 2 runs main.py:86-119's step on the batched device
+    path -- teacher = global view 1, student = global view 2 + two 16 x 16 local crops (their own width group through the encoder:
+    N = 2 tokens), BarlowTwinsLoss(ncrops = L + 2) averaging L + 1 terms -- against the CPU oracle on the same weights and crops; then
+    the whole path from log-mels (augmentation launches included) for three steps."""
+    from oracle import step as ostep, heads as oheads
+    L, B = 2, 8
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=B, crop_frames=96, projector_hidden_dim=256, projector_out_dim=64, local_crops_number=L)
+    tr = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=B, clip_samples=15200, seed=0, from_waveform=False)
+    assert tr.criterion.ncrops == L + 2
+    g = torch.Generator().manual_seed(8)
+    base = torch.randn(B, 1, 64, 96, generator=g)
+    crops = [base + 0.3 * torch.randn(B, 1, 64, 96, generator=g), base + 0.3 * torch.randn(B, 1, 64, 96, generator=g)]
+    crops += [base[:, :, 20:36, 16 * (l + 1):16 * (l + 2)].clone() + 0.1 * torch.randn(B, 1, 16, 16, generator=g) for l in range(L)]
+    sd = {k: v.detach().float().cpu().clone() for k, v in tr.online.state_dict().items() if "num_batches" not in k}
+    loss = float(tr.step_views([c.to(dev) for c in crops]))
+    zt, _ = ostep.network_forward(sd, crops[:1], 1, 3, (4, 6))
+    zs, _ = ostep.network_forward(sd, crops[1:], L + 1, 3, (4, 6))
+    ref, _ = oheads.bt_forward(zs, zt, L + 2, ngcrops_each=1)
+    print("trainer, local crops: loss", loss, "oracle", float(ref))
+    assert abs(loss - float(ref)) <= 3e-2 * abs(float(ref)), (loss, float(ref))
+    grads = flat_grads(tr)
+    bad = [k for k, gr in grads.items() if not (torch.isfinite(gr).all() and float(gr.abs().max()) > 0)]
+    assert not bad, bad[:5]
+    with pytest.raises(NotImplementedError):
+        tr.enable_graph()
+    # from log-mels: the augmentation's two launches (globals, locals) feed the same step; the loss falls on a fixed batch
+    lms = torch.randn(B, 1, 64, 96, generator=g).to(dev)
+    losses = [float(tr.step(lms)) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    with pytest.raises(NotImplementedError):
+        BarlowTwinsTrainer(cfg, dev, mode="byol", batch_per_rank=B, clip_samples=15200, seed=0, from_waveform=False)
+
+
 @pytest.mark.parametrize("mode", ["bt", "byol"])
 def test_graph_replay_equals_eager(dev, mode):
     """the device part of the step captured into ONE HIP graph (BarlowTwinsTrainer.enable_graph) and replayed takes

@@ -140,7 +140,7 @@ def _worker_body(rank, world, port, q):
     for k, p in enumerate(params):                          # three "block" parameters living at [20,30), [30,40), [60,70)
         off = [20, 30, 60][k]
         engine.register_grad_sink(p, flat.grads[off:off + 10], flat)
-    sync = GradSync(flat)
+    sync = GradSync(flat, min_block_bytes=0)
     sync.block_done(params[:2])                             # one contiguous run [20, 40)
     sync.block_done([params[2], params[0]])                 # scattered: [60, 70) and (again, idempotent ranges are NOT allowed) -> see below
     ok_sync = False
@@ -154,7 +154,7 @@ def _worker_body(rank, world, port, q):
     engine.register_grad_sink(q1, flat2.grads[80:88], flat2)
     flat2.grads[0:8] = rank + 1.0
     flat2.grads[80:88] = 10.0 * (rank + 1)
-    sync2 = flat2.sync = GradSync(flat2)
+    sync2 = flat2.sync = GradSync(flat2, min_block_bytes=0)
     # hooks are instance state: each parameter's block hook is the GradSync of the flat buffer that holds ITS sink, so two live
     # trainers never reduce each other's ranges (the process-global engine.BLOCK_DONE_HOOK)
     flat.sync = sync
@@ -166,6 +166,23 @@ def _worker_body(rank, world, port, q):
     tot = sum(range(1, world + 1))
     ok_sync = (torch.all(flat2.grads[0:8] == tot) and torch.all(flat2.grads[80:88] == 10.0 * tot)
                and torch.all(flat2.grads[8:80] == 100.0 * tot) and torch.all(flat2.grads[88:] == 0)).item()
+    # runs below min_block_bytes (a block's few-KB LayerNorm / bias vectors) are NOT reduced from the block hook but exactly once, with
+    # their neighbours, by finish() (twelve latency-bound collectives per step)
+    flat3 = Flat()
+    flat3.n_train = 64
+    flat3.grads = torch.zeros(64)
+    r0, r1 = torch.nn.Parameter(torch.zeros(16)), torch.nn.Parameter(torch.zeros(8))
+    engine.register_grad_sink(r0, flat3.grads[0:16], flat3)        # 64 bytes: reduced from the hook
+    engine.register_grad_sink(r1, flat3.grads[40:48], flat3)       # 32 bytes: deferred
+    flat3.grads[0:16] = rank + 1.0
+    flat3.grads[40:48] = 2.0 * (rank + 1)
+    sync3 = flat3.sync = GradSync(flat3, min_block_bytes=64)
+    sync3.block_done([r0, r1])
+    assert sync3._ready_ranges == [(0, 16)], sync3._ready_ranges
+    flat3.grads[16:40] = 3.0 * (rank + 1)
+    sync3.finish()
+    ok_sync = ok_sync and (torch.all(flat3.grads[0:16] == tot) and torch.all(flat3.grads[40:48] == 2.0 * tot)
+                           and torch.all(flat3.grads[16:40] == 3.0 * tot) and torch.all(flat3.grads[48:] == 0)).item()
     _double_backward_guard(rank, world)
     to_np = lambda d: {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in d.items()}   # no shared-memory tensors in the queue
     q.put((rank, bool(ok_bn), bool(ok_sync), None, to_np(res_exact), to_np(res_lit)))

@@ -403,6 +403,37 @@ def test_batched_augment_matches_sequential_oracle(dev):
     assert [r["rrc"] for r in ba.records] == [tuple(r["rrc"]) for r in orc.records[-2 * B:]]
 
 
+def test_batched_augment_local_crops_and_gnoise_match_sequential_oracle(dev):
+    """the batched device path with L = 2 local crops (utils/transforms.py:38-47,54-55) and --Gnoise
+    (utils/transforms.py:21-22) == the oracle's sequential per-clip pipeline: same RNG call order (two globals -- each mixup, noise
+    lambda, crop, fade -- then the L local crops of the un-mixed clip), same bank evolution over 3 batches, identical normal draws
+    handed to both sides."""
+    from oracle import augment as oaug
+    B, T_, L = 4, 208, 2
+    rng = np.random.RandomState(6)
+    nrm = np.random.RandomState(7)
+    queue = []
+    ba = aug.BatchedPairAugment(dev, 64, T_, T_, seed=13, n_memory=10, local_crops_number=L, local_crops_size=(16, 16), gnoise=True)
+    orc = oaug.PairTransformOracle(crop_frames=T_, seed=13, n_memory=10, local_crops_number=L, local_crops_size=(16, 16), gnoise=True,
+                                   normal_fn=lambda shape: queue.pop(0))
+    for it in range(3):
+        clips = (rng.randn(B, 64, T_) * 1.3 - 0.2).astype(np.float32)
+        normals = nrm.randn(2, B, 64, T_).astype(np.float32)                 # [view, clip]: the layout of the batched launch
+        ba.next_slots(B).copy_(T(clips, dev))
+        ba.normal_override = T(normals.reshape(2 * B, 64, T_), dev)
+        crops = ba(B)
+        assert len(crops) == 2 + L and crops[0].shape == (B, 1, 64, T_) and crops[2].shape == (B, 1, 16, 16)
+        got = [c.cpu().numpy() for c in crops]
+        for b in range(B):
+            queue[:] = [normals[0, b][None], normals[1, b][None]]            # the oracle draws clip b's two global views in order
+            ref = orc(clips[b][None])
+            for v in range(2 + L):
+                assert np.abs(got[v][b] - ref[v]).max() < 3e-4, (it, b, v, np.abs(got[v][b] - ref[v]).max())
+    rec = [r for r in ba.records]
+    assert [tuple(r["rrc"]) for r in rec] == [tuple(r["rrc"]) for r in orc.records[-(2 + L) * B:]]
+    assert [r["lambd"] for r in rec if "lambd" in r] == [r["lambd"] for r in orc.records[-(2 + L) * B:] if "lambd" in r]
+
+
 def test_log_mixup_exp_and_normalize_golden(dev, golden):
     g = golden("augment")
     for k in range(4):
