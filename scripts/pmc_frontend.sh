@@ -1,0 +1,25 @@
+#!/bin/bash
+# PMC counters of the frontend / augmentation kernels (scripts/bench_frontend.py), one rocprofv3 pass per counter group.
+#   usage (GPU box): bash scripts/pmc_frontend.sh OUTDIR
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=${1:-gpurun_out/r04/pmc_fe}; mkdir -p $O
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_IDX_ACTIVE" \
+           "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- python3 scripts/bench_frontend.py > $O/g$i.log 2>&1 || echo "group $i failed"
+done
+python3 - $O <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(sys.argv[1] + "/g*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "logmel" in k or "augment" in k:
+            acc["logmel" if "logmel" in k else "augment"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:28s} {sum(v) / len(v):16.0f}   (n={len(v)})")
+PY

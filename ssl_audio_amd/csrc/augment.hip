@@ -10,12 +10,12 @@
 // LDS and adds the fade slope.  The canvas is never built in memory.
 // Sampling is NOT done here: (alpha, bank slot, i, j, h, w, head, tail) arrive as explicit parameters so the
 // CPU oracle and this kernel consume identical draws.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
 
 namespace {
 
-constexpr int LDS_W = 132;          // source columns per tile (incl. cubic halo)
 constexpr int LDS_H = 64;           // source rows per tile (crop height <= canvas height)
 constexpr float kEps32 = 1.1920929e-07f;
 constexpr float kA = -0.75f;        // PyTorch bicubic coefficient
@@ -35,6 +35,10 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
   w[3] = ((kA * x3 - 5.f * kA) * x3 + 8.f * kA) * x3 - 4.f * kA;
 }
 
+// LDS_W = source columns per tile (incl. the cubic halo), TXW = output columns per slab.  <132, 64>: 34 KiB of LDS, four workgroups per
+// CU; <72, 32>: 18 KiB, eight per CU -- a workgroup's load phase and its interpolation phase are serial, so more, smaller workgroups
+// keep the memory pipe busier (at 8 % more halo columns fetched twice).
+template <int LDS_W, int TXW>
 __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ lms, int64_t clip_stride, const int* __restrict__ src_slot,
                                                       const int* __restrict__ mix_slot, const ViewParams* __restrict__ params,
                                                       float* __restrict__ out, int F_in, int T_in, int canvas_h, int canvas_w, int F_out,
@@ -62,29 +66,56 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   const int xhi = min(cw - 1, (int)floorf(__fmul_rn(sx, (float)(t0 + nt - 1))) + 2);
   const int wt = xhi - xlo + 1;  // host guarantees wt <= LDS_W via TT
 
-  // ---- stage 1: mixed source tile [ch x wt].  Thread -> (row pair, column): no per-element division, a wave reads 64 consecutive
-  // source columns of one row (256 contiguous bytes of x and of the bank entry z)
-  for (int yy = threadIdx.x >> 7; yy < ch; yy += 2) {
-    const int r = ci + yy - py;
-    const bool row_in = r >= 0 && r < F_in;
-    for (int xx = threadIdx.x & 127; xx < wt; xx += 128) {
-      const int cc = cj + xlo + xx - px;  // input coordinates
-      float v = 0.f;
-      if (row_in && cc >= 0 && cc < T_in) {
-        v = x[(int64_t)r * T_in + cc];
-        if (z) v = logf(wa * expf(v) + wb * expf(z[(int64_t)r * T_in + cc]) + kEps32);
-        if (nz) v = logf((1.f - pr.lambd) * expf(v) + expf(pr.lambd * nz[(int64_t)r * T_in + cc]) + kEps32);
+  // ---- stage 1: mixed source tile [ch x wt].  Thread -> (column, row parity): a wave reads 64 consecutive source columns of one row
+  // (256 contiguous bytes of x, of the bank entry z and of the noise grid).  EIGHT rows' loads are issued before the first value is
+  // used: with one row per iteration every iteration paid a full HBM round trip (the loop was latency-bound: 32 dependent trips per
+  // block), now there are four batches of up to 24 independent loads.
+  constexpr int CT = TXW * 2, RP = 256 / CT;          // column threads per row, row phases (CT = 128: 2 phases; 64: 4)
+  for (int xx = threadIdx.x % CT; xx < wt; xx += CT) {
+    const int cc = cj + xlo + xx - px;  // input coordinates
+    const bool col_in = cc >= 0 && cc < T_in;
+    for (int yy0 = threadIdx.x / CT; yy0 < ch; yy0 += 8 * RP) {
+      float xv[8], zv[8], nv[8];
+      bool ok[8];
+      // UNCONDITIONAL loads from an always-valid (clamped) address, selected afterwards: a predicated load compiles to a branch whose
+      // join waits for it (`s_waitcnt vmcnt(0)` after every row: 32 serial HBM round trips per block -- what this loop used to cost)
+      const float* zs = z ? z : x;
+      const float* ns = nz ? nz : x;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int yy = yy0 + RP * u, r = ci + yy - py;
+        ok[u] = col_in && yy < ch && r >= 0 && r < F_in;
+        const int64_t off = (int64_t)min(max(r, 0), F_in - 1) * T_in + min(max(cc, 0), T_in - 1);
+        xv[u] = x[off];
+        zv[u] = zs[off];
+        nv[u] = ns[off];
       }
-      tile[yy * LDS_W + xx] = v;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = ok[u] ? xv[u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int yy = yy0 + RP * u;
+        float v = xv[u];
+        if (ok[u]) {
+          // v_exp_f32 / v_log_f32 (1 ulp each) instead of libm's expf / logf: those were ~1 500 of the 2 200 vector instructions a
+          // wave executed (PMC, profiles/r04_frontend_pmc.txt); the results move by <= 1e-6 (the golden tests hold 1e-5)
+          if (z) v = __logf(wa * __expf(v) + wb * __expf(zv[u]) + kEps32);
+          if (nz) v = __logf((1.f - pr.lambd) * __expf(v) + __expf(pr.lambd * nv[u]) + kEps32);
+        }
+        if (yy < ch) tile[yy * LDS_W + xx] = v;
+      }
     }
   }
   __syncthreads();
 
-  // ---- stage 2: bicubic + fade.  Thread -> output column tx (fixed) x rows fy = rg, rg + 4, ...: the horizontal taps and weights are
-  // computed once per thread, the vertical ones are wave-uniform, a wave stores 64 consecutive frames of one mel row (256 bytes)
+  // ---- stage 2: bicubic + fade.  Thread -> output column tx (fixed) x a run of CONSECUTIVE output rows: the horizontal taps and
+  // weights are computed once per thread, and the horizontally interpolated value h(r) of a source row is computed once and kept in a
+  // four-deep register window that slides down the tile (consecutive output rows share three of their four source rows at scale <= 1):
+  // 4-8 LDS reads per output instead of 16.  The vertical taps are wave-uniform; a wave stores 64 consecutive frames of one mel row.
   const float fade_step = T_out > 1 ? (pr.tail - pr.head) / (float)(T_out - 1) : 0.f;
   float* o = out + (int64_t)view * F_out * T_out;
-  const int tx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  constexpr int NG = 256 / TXW;                       // output row groups (4 or 8)
+  const int tx = threadIdx.x % TXW, rg = threadIdx.x / TXW;
   if (tx < nt) {
     const int t = t0 + tx;
     // rounded products (no FMA contraction into the fraction): PyTorch's CPU kernel rounds scale*index to fp32 first
@@ -103,20 +134,38 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
       const int half = T_out / 2;
       fade = (t < half) ? pr.head + fade_step * (float)t : pr.tail - fade_step * (float)(T_out - 1 - t);
     }
-    for (int fy = rg; fy < F_out; fy += 4) {
+    auto hrow = [&](int r) {                 // source row r (clamped to the crop), interpolated at this thread's column
+      const float* row = tile + min(max(r, 0), ch - 1) * LDS_W;
+      return row[cx[0]] * wx[0] + row[cx[1]] * wx[1] + row[cx[2]] * wx[2] + row[cx[3]] * wx[3];
+    };
+    const int rows_per = (F_out + NG - 1) / NG;
+    const int fy_end = min(F_out, (rg + 1) * rows_per);
+    int rwin = 0;
+    bool have = false;
+    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;   // h(rwin) .. h(rwin + 3)
+    for (int fy = rg * rows_per; fy < fy_end; ++fy) {
       float ry = sy * (float)fy;
       asm volatile("" : "+v"(ry));
       const float fyf = floorf(ry);
       float wy[4];
       cubic_w(ry - fyf, wy);
-      const int iy = (int)fyf;
-      float acc = 0.f;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const float* row = tile + min(max(iy - 1 + a, 0), ch - 1) * LDS_W;
-        const float r = row[cx[0]] * wx[0] + row[cx[1]] * wx[1] + row[cx[2]] * wx[2] + row[cx[3]] * wx[3];
-        acc += r * wy[a];
+      const int want = (int)fyf - 1;         // wave-uniform: the window moves in uniform control flow
+      if (!have || want - rwin >= 4) {
+        h0 = hrow(want); h1 = hrow(want + 1); h2 = hrow(want + 2); h3 = hrow(want + 3);
+        rwin = want;
+        have = true;
+      } else {
+        while (rwin < want) {
+          h0 = h1; h1 = h2; h2 = h3;
+          h3 = hrow(rwin + 4);
+          ++rwin;
+        }
       }
+      float acc = 0.f;
+      acc += h0 * wy[0];
+      acc += h1 * wy[1];
+      acc += h2 * wy[2];
+      acc += h3 * wy[3];
       if (do_fade) acc += fade;
       o[(int64_t)fy * T_out + t] = acc;
     }
@@ -198,12 +247,23 @@ extern "C" int sa_augment_views(const float* lms, int64_t clip_stride, const int
   SA_CHECK_ARG(canvas_h <= LDS_H, "sa_augment_views: canvas height %d exceeds the %d-row LDS tile", canvas_h, LDS_H);
   SA_CHECK_ARG(F_out > 0 && T_out > 0 && F_in > 0 && T_in > 0 && max_w_ratio > 0.f, "sa_augment_views: bad sizes");
   // slab width so that ceil(TT * ratio) + 4 source columns fit the LDS tile; ratio = max crop width / T_out
-  int TT = (int)floorf((float)(LDS_W - 5) / max_w_ratio);
-  if (TT > 64) TT = 64;
-  SA_CHECK_ARG(TT >= 1, "sa_augment_views: crop/out width ratio %f too large", max_w_ratio);
-  dim3 grid((T_out + TT - 1) / TT, n_views);
-  hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, (hipStream_t)stream, lms, clip_stride, src_slot, mix_slot,
-                     reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade, noise);
+  static const char* wide_env = getenv("SA_AUG_WIDE");      // experiment knob: 1 = the 132-column tile / 64-column slabs only
+  const bool wide = wide_env && wide_env[0] == '1';
+  int TT = (int)floorf((float)((wide ? 132 : 72) - 5) / max_w_ratio);
+  const int cap = wide ? 64 : 32;
+  if (TT > cap) TT = cap;
+  if (!wide && TT >= 8) {
+    dim3 grid((T_out + TT - 1) / TT, n_views);
+    hipLaunchKernelGGL((augment_kernel<72, 32>), grid, dim3(256), 0, (hipStream_t)stream, lms, clip_stride, src_slot, mix_slot,
+                       reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade, noise);
+  } else {                                                  // steep down-sampling (local crops of a long clip): the wide source tile
+    TT = (int)floorf((float)(132 - 5) / max_w_ratio);
+    if (TT > 64) TT = 64;
+    SA_CHECK_ARG(TT >= 1, "sa_augment_views: crop/out width ratio %f too large", max_w_ratio);
+    dim3 grid((T_out + TT - 1) / TT, n_views);
+    hipLaunchKernelGGL((augment_kernel<132, 64>), grid, dim3(256), 0, (hipStream_t)stream, lms, clip_stride, src_slot, mix_slot,
+                       reinterpret_cast<const ViewParams*>(params), out, F_in, T_in, canvas_h, canvas_w, F_out, T_out, TT, do_fade, noise);
+  }
   SA_LAUNCH_CHECK("sa_augment_views");
   return 0;
 }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                                                      float* __restrict__ out, int64_t out_stride, int n_frames, int T_out, int start,
                                                      float mean, float inv_std, float pad_value, int hop) {
   __shared__ float ex_re[4][8 * XS], ex_im[4][8 * XS];   // per-wave exchange / spectrum buffers
-  __shared__ float pw[4][NBINS + 3];
+  __shared__ float pw[4][NBINS + MAXLEN_CAP + 3];      // power spectrum + a zero tail: band `lo + q` never needs a clamp
   __shared__ float stage[NMEL][FR_PER_BLOCK + 1];
   __shared__ float melw_s[MAXLEN_CAP * NMEL];            // the filter table, staged once per workgroup
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -83,9 +83,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
   const bool mel_lds = maxlen <= MAXLEN_CAP;
   if (mel_lds)
     for (int i = threadIdx.x; i < maxlen * NMEL; i += 256) melw_s[i] = melw[i];
-  float2 win[8], twa[8], twb[8], tws[8];
-#pragma unroll
-  for (int n1 = 0; n1 < 8; ++n1) win[n1] = *reinterpret_cast<const float2*>(window + 2 * (64 * n1 + lane));
+  for (int i = lane; i < MAXLEN_CAP + 2; i += 64) pw[w][NBINS + i] = 0.f;
+  float2 twa[8], twb[8], tws[8];
 #pragma unroll
   for (int k1 = 1; k1 < 8; ++k1) twa[k1] = tw[(2 * lane * k1) & 1023];
 #pragma unroll
@@ -116,9 +115,13 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     if (frame_live(f + 1)) load_frame(t + 1, smp_next);       // the next frame's samples travel while this one is transformed
     if (live) {
       // ---- window: lane n2 holds z[64*n1 + n2], n1 = 0..7
+      // (the window is re-read per frame: 4 KiB that stay in the CU's L1; holding it in 16 registers cost a wave per SIMD)
       cpx v[8];
 #pragma unroll
-      for (int n1 = 0; n1 < 8; ++n1) v[n1] = {smp[n1].x * win[n1].x, smp[n1].y * win[n1].y};
+      for (int n1 = 0; n1 < 8; ++n1) {
+        const float2 wn = *reinterpret_cast<const float2*>(window + 2 * (64 * n1 + lane));
+        v[n1] = {smp[n1].x * wn.x, smp[n1].y * wn.y};
+      }
       // ---- pass A: DFT8 over n1, twiddle W_512^{n2*k1} = W_1024^{2*n2*k1}
       dft8(v);
 #pragma unroll
@@ -137,15 +140,20 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #pragma unroll
       for (int c = 0; c < 8; ++c) { xr[k1 * XS + 9 * c + b] = v[c].re; xi[k1 * XS + 9 * c + b] = v[c].im; }
       __builtin_amdgcn_wave_barrier();
-      // ---- pass B2: lane = (c, k1) [lane = 8*c + k1]; DFT8 over b of u[k1][c][b] -> Z[k1 + 8c + 64d]
-      const int c2 = lane >> 3, k2 = lane & 7;
+      // ---- pass B2: lane = (k1, c) [lane = 8*k1 + c]; DFT8 over b of u[k1][c][b] -> Z[k1 + 8c + 64d].  (With lane = 8*c + k1 the
+      // reads of rows k1 and k1 + 4 met in one bank: the row stride of 72 floats is 8 mod 32.)
+      const int k2 = lane >> 3, c2 = lane & 7;
 #pragma unroll
       for (int bb = 0; bb < 8; ++bb) v[bb] = {xr[k2 * XS + 9 * c2 + bb], xi[k2 * XS + 9 * c2 + bb]};
       dft8(v);
       __builtin_amdgcn_wave_barrier();
-      // natural-order spectrum Z[k], k = k2 + 8*c2 + 64*d  (reuse the exchange buffers as flat [512])
+      // natural-order spectrum Z[k], k = k2 + 8*c2 + 64*d, kept at position k + 4 * (k >> 5) of the exchange buffers (576 floats:
+      // the pad makes this store, whose lanes step by 8, and the loads below conflict-free)
 #pragma unroll
-      for (int d = 0; d < 8; ++d) { xr[k2 + 8 * c2 + 64 * d] = v[d].re; xi[k2 + 8 * c2 + 64 * d] = v[d].im; }
+      for (int d = 0; d < 8; ++d) {
+        const int k = k2 + 8 * c2 + 64 * d;
+        xr[k + 4 * (k >> 5)] = v[d].re; xi[k + 4 * (k >> 5)] = v[d].im;
+      }
       __builtin_amdgcn_wave_barrier();
       // ---- real-input split + power: X[k] = E[k] + W_1024^k O[k]
       float* P = pw[w];
@@ -153,7 +161,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
         const int kc = (NC - k) & (NC - 1);
-        const cpx zk = {xr[k], xi[k]}, zc = {xr[kc], -xi[kc]};          // Z[k], conj(Z[N-k])
+        const int pk = k + 4 * (k >> 5), pc = kc + 4 * (kc >> 5);
+        const cpx zk = {xr[pk], xi[pk]}, zc = {xr[pc], -xi[pc]};          // Z[k], conj(Z[N-k])
         const cpx e = {0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im)};
         const cpx dd = csub(zk, zc);
         const cpx o = {0.5f * dd.im, -0.5f * dd.re};                     // (-i/2) (Z[k] - conj(Z[N-k]))
@@ -168,13 +177,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
       // ---- mel band `lane`: sum over its bin range
       float m = 0.f;
       if (mel_lds) {
+        // (weights past a band's end are zero and P has a zero tail past bin 512: no clamp, one address per lane, immediate offsets)
+        const float* Pl = P + lo;
+        const float* Wl = melw_s + lane;
 #pragma unroll 8
-        for (int q = 0; q < maxlen; ++q) m += melw_s[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];   // same order of additions as before
+        for (int q = 0; q < maxlen; ++q) m += Wl[q * NMEL] * Pl[q];                                   // same order of additions as before
       } else {
 #pragma unroll 8
         for (int q = 0; q < maxlen; ++q) m += melw[q * NMEL + lane] * P[min(lo + q, NBINS - 1)];
       }
-      result = (logf(m + 1.1920929e-07f) - mean) * inv_std;
+      result = (__logf(m + 1.1920929e-07f) - mean) * inv_std;     // v_log_f32: 1 ulp
       __builtin_amdgcn_wave_barrier();
     }
     stage[lane][w * FR_PER_WAVE + f] = result;
