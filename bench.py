@@ -374,6 +374,8 @@ def main():
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)          # anything printed from here on (RCCL's banner when its first communicator only comes up at the barrier below:
+                               # one-rank runs) goes to stderr: stdout stays the ONE JSON line
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
