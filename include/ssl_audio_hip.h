@@ -154,6 +154,23 @@ int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const floa
 int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
                   int32_t M, int32_t N, int32_t K, float alpha, void* stream);
 int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream);
+/* The loss term fused around its three collectives (ABI v5; SURVEY.md section 2.3 "K7", utils/loss.py:15-30): five launches instead of
+ * the fifteen of the piecewise schedule above, same arithmetic.
+ *   sa_bt_stats2        stats [2][2][D] = per view (mean, M2) of the local rows of z1, z2 [B][D] (row stride ld)       -> all-gather
+ *   sa_bt_corr          all_stats [W][2][2][D]: Chan combine over the W ranks (B rows each) -> mean / rstd [2][D], running buffers
+ *                       updated with view 1 then view 2 (bn(z1), bn(z2): utils/loss.py:17), z1n / z2n [B][D] (saved for the backward)
+ *                       and c [D][D] = inv_n * z1n^T z2n (the local partial of utils/loss.py:19)                     -> all-reduce
+ *   sa_bt_loss_grad     (above)
+ *   sa_bt_bwd_products  dzn [2][B][D] = inv_n * (z2n G^T | z1n G) and sums [2][2][D] = per view (sum_b dzn, sum_b dzn * zn) -> all-reduce
+ *   sa_bt_bwd_apply     dz_v = scale * rstd_v * (dzn_v - s1_v * inv_n - zn_v * s2_v * inv_n); out_scale: device scalar (dloss) or NULL */
+int sa_bt_stats2(const float* z1, const float* z2, int64_t ld, int32_t B, int32_t D, float* stats, void* stream);
+int sa_bt_corr(const float* z1, const float* z2, int64_t ld, int32_t B, int32_t D, const float* all_stats, int32_t W, float eps,
+               float momentum, float inv_n, float* mean, float* rstd, float* running_mean, float* running_var, float* z1n, float* z2n,
+               float* c, void* stream);
+int sa_bt_bwd_products(const float* z1n, const float* z2n, int32_t B, int32_t D, const float* G, float inv_n, float* dzn, float* sums,
+                       void* stream);
+int sa_bt_bwd_apply(const float* z1n, const float* z2n, int32_t B, int32_t D, const float* rstd, const float* dzn, const float* sums,
+                    float inv_n, const float* out_scale, float* dz1, float* dz2, void* stream);
 
 /* ------------------------------------------------------------------ optimiser / EMA on flat fp32 buffers
  * AdamW: torch.optim.AdamW semantics (main_bt_byol.py:312-313); p_bf16 (optional) receives the bf16 copy the

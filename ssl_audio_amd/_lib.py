@@ -93,6 +93,10 @@ _SIGNATURES = {
     "sa_bn_finalize": [P, I64, I32, I32, I32, F32, F32, P, P, P, P, P],
     "sa_matmul_f32": [P, I64, I64, P, I64, I64, P, I64, I32, I32, I32, F32, P],
     "sa_bt_loss_grad": [P, I32, F32, F32, I32, P, P, P],
+    "sa_bt_stats2": [P, P, I64, I32, I32, P, P],
+    "sa_bt_corr": [P, P, I64, I32, I32, P, I32, F32, F32, F32, P, P, P, P, P, P, P, P],
+    "sa_bt_bwd_products": [P, P, I32, I32, P, F32, P, P, P],
+    "sa_bt_bwd_apply": [P, P, I32, I32, P, P, P, F32, P, P, P, P],
     "sa_adamw_step": [P, P, P, P, I64, F32, F32, F32, F32, F32, I32, F32, P, P],
     "sa_ema_update": [P, P, I64, F32, P],
     "sa_adamw_step_dev": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, P, P, P],

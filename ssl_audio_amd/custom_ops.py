@@ -46,6 +46,12 @@ SCHEMAS = {
                      "float inv_n, *, Tensor? out_scale=None, Tensor(a!)? dx_f32=None, Tensor(b!)? dx_bf16=None) -> ()"),
     "matmul_f32": ("sa_matmul_f32", "(Tensor A, Tensor B, Tensor(a!) out, *, bool trans_a=False, bool trans_b=False, float alpha=1.0) -> ()"),
     "bt_loss_grad": ("sa_bt_loss_grad", "(Tensor c, float alpha, float lmbda, bool hsic, Tensor(a!) loss, Tensor(b!)? G=None) -> ()"),
+    "bt_stats2": ("sa_bt_stats2", "(Tensor z1, Tensor z2, Tensor(a!) stats) -> ()"),
+    "bt_corr": ("sa_bt_corr", "(Tensor z1, Tensor z2, Tensor all_stats, float eps, float momentum, float inv_n, Tensor(a!) mean, Tensor(b!) rstd, "
+                "Tensor(c!)? running_mean, Tensor(d!)? running_var, Tensor(e!) z1n, Tensor(f!) z2n, Tensor(g!) c) -> ()"),
+    "bt_bwd_products": ("sa_bt_bwd_products", "(Tensor z1n, Tensor z2n, Tensor G, float inv_n, Tensor(a!) dzn, Tensor(b!) sums) -> ()"),
+    "bt_bwd_apply": ("sa_bt_bwd_apply", "(Tensor z1n, Tensor z2n, Tensor rstd, Tensor dzn, Tensor sums, float inv_n, Tensor? out_scale, "
+                     "Tensor(a!) dz1, Tensor(b!) dz2) -> ()"),
     "adamw_step": ("sa_adamw_step", "(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, float wd, int step, "
                    "float grad_scale=1.0, Tensor(d!)? p_bf16=None) -> ()"),
     "lars_step": ("sa_lars_step", "(Tensor(a!) p, Tensor g, Tensor(b!) mu, float lr, float wd, float momentum, float eta, bool adapt, "

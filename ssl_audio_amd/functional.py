@@ -252,48 +252,39 @@ class BTLossFn(torch.autograd.Function):
         dev = z1.device
         W = sdist.get_world_size()
         local_bn = bool(literal_ddp and W > 1)
-        z = (z1.contiguous().float(), z2.contiguous().float())
+        z1, z2 = z1.contiguous().float(), z2.contiguous().float()
+        if z1.stride(0) != z2.stride(0):
+            z2 = z2.clone(memory_format=torch.contiguous_format)
+        # five launches around the three collectives (csrc/bt_fused.hip; the piecewise kernels stay for the projector's BatchNorm)
         stats = torch.empty(2, 2, D, device=dev)                 # [view][mean | M2][D]
-        for v in range(2):
-            ops.bn_colstats(z[v], stats[v, 0], stats[v, 1])
+        ops.bt_stats2(z1, z2, stats)
         allst = stats.unsqueeze(0) if local_bn else sdist.all_gather_rows(stats)        # [W, 2, 2, D]: one all-gather for both views
-        mean, rstd = torch.empty(2, D, device=dev), torch.empty(2, D, device=dev)
-        norm = []
-        for v in range(2):                                       # bn(z1) then bn(z2): running stats see both, in this order
-            ops.bn_finalize(allst[:, v], B, BN_EPS, BN_MOMENTUM, mean[v], rstd[v], running_mean, running_var)
-            zn = torch.empty(B, D, device=dev)
-            ops.bn_apply(z[v], mean[v], rstd[v], None, None, False, y_f32=zn)
-            norm.append(zn)
         n_eff = B if (literal_ddp or W == 1) else B * W
+        mean, rstd = torch.empty(2, D, device=dev), torch.empty(2, D, device=dev)
+        z1n, z2n = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
         c = torch.empty(D, D, device=dev)
-        ops.matmul_f32(norm[0], norm[1], c, trans_a=True, alpha=1.0 / n_eff)
-        sdist.all_reduce_sum_(c)                             # utils/loss.py:20-21
+        # bn(z1) then bn(z2): the running buffers see both, in this order (utils/loss.py:17); c = z1n^T z2n / n (:19)
+        ops.bt_corr(z1, z2, allst.contiguous(), BN_EPS, BN_MOMENTUM, 1.0 / n_eff, mean, rstd, running_mean, running_var, z1n, z2n, c)
+        sdist.all_reduce_sum_(c)                                 # utils/loss.py:20-21
         loss = torch.empty(1, device=dev)
         G = torch.empty(D, D, device=dev)
         ops.bt_loss_grad(c, alpha, lmbda, hsic, loss, G)
-        ctx.save_for_backward(z[0], z[1], norm[0], norm[1], mean, rstd, G)
+        ctx.save_for_backward(z1n, z2n, rstd, G)
         ctx.cfg = (n_eff, local_bn)
         return loss[0]
 
     @staticmethod
     def backward(ctx, dloss):
-        z1, z2, z1n, z2n, mean, rstd, G = ctx.saved_tensors
+        z1n, z2n, rstd, G = ctx.saved_tensors
         n_eff, local_bn = ctx.cfg
-        B, D = z1.shape
-        dev = z1.device
-        dz1n, dz2n = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
-        ops.matmul_f32(z2n, G, dz1n, trans_b=True, alpha=1.0 / n_eff)   # dz1n = z2n G^T / n
-        ops.matmul_f32(z1n, G, dz2n, alpha=1.0 / n_eff)                  # dz2n = z1n G   / n
-        scale = dloss.reshape(1).float().contiguous()
-        s = torch.empty(2, 2, D, device=dev)                             # [view][s1 | s2][D]: one all-reduce for both views
-        for v, (z, dzn) in enumerate(((z1, dz1n), (z2, dz2n))):
-            ops.bn_bwd_stats(dzn, z, mean[v], rstd[v], None, None, False, s[v, 0], s[v, 1])
+        B, D = z1n.shape
+        dev = z1n.device
+        dzn = torch.empty(2, B, D, device=dev)
+        s = torch.empty(2, 2, D, device=dev)                     # [view][s1 | s2][D]: one all-reduce for both views
+        ops.bt_bwd_products(z1n, z2n, G, 1.0 / n_eff, dzn, s)    # dz1n = z2n G^T / n, dz2n = z1n G / n and their column sums
         if not local_bn:
             sdist.all_reduce_sum_(s)
-        outs = []
-        for v, (z, dzn) in enumerate(((z1, dz1n), (z2, dz2n))):
-            dz = torch.empty(B, D, device=dev)
-            ops.bn_bwd_apply(dzn, z, mean[v], rstd[v], None, None, False, s[v, 0], s[v, 1], 1.0 / (B if local_bn else n_eff), out_scale=scale,
-                             dx_f32=dz)
-            outs.append(dz)
-        return outs[0], outs[1], None, None, None, None, None, None
+        scale = dloss.reshape(1).float().contiguous()
+        dz1, dz2 = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
+        ops.bt_bwd_apply(z1n, z2n, rstd, dzn, s, 1.0 / (B if local_bn else n_eff), scale, dz1, dz2)
+        return dz1, dz2, None, None, None, None, None, None

@@ -312,6 +312,34 @@ def bt_loss_grad(c, alpha, lmbda, hsic, loss, G=None):
           "sa_bt_loss_grad")
 
 
+def bt_stats2(z1, z2, stats):
+    B, D = z1.shape
+    check(lib().sa_bt_stats2(_p(_req(z1, F32, "z1")), _p(_req(z2, F32, "z2")), z1.stride(0), B, D, _p(_req(stats, F32, "stats")), _stream()),
+          "sa_bt_stats2")
+
+
+def bt_corr(z1, z2, all_stats, eps, momentum, inv_n, mean, rstd, running_mean, running_var, z1n, z2n, c):
+    B, D = z1.shape
+    W = all_stats.shape[0]
+    if z1.stride(0) != z2.stride(0) or tuple(all_stats.shape[1:]) != (2, 2, D) or not all_stats.is_contiguous():
+        raise ValueError("bt_corr: z1 / z2 must share a row stride, all_stats must be a contiguous [W, 2, 2, D]")
+    check(lib().sa_bt_corr(_p(_req(z1, F32, "z1")), _p(_req(z2, F32, "z2")), z1.stride(0), B, D, _p(_req(all_stats, F32, "all_stats")), W, float(eps),
+                           float(momentum), float(inv_n), _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(z1n), _p(z2n), _p(c), _stream()),
+          "sa_bt_corr")
+
+
+def bt_bwd_products(z1n, z2n, G, inv_n, dzn, sums):
+    B, D = z1n.shape
+    check(lib().sa_bt_bwd_products(_p(_req(z1n, F32, "z1n")), _p(_req(z2n, F32, "z2n")), B, D, _p(_req(G, F32, "G")), float(inv_n), _p(dzn), _p(sums),
+                                   _stream()), "sa_bt_bwd_products")
+
+
+def bt_bwd_apply(z1n, z2n, rstd, dzn, sums, inv_n, out_scale, dz1, dz2):
+    B, D = z1n.shape
+    check(lib().sa_bt_bwd_apply(_p(_req(z1n, F32, "z1n")), _p(_req(z2n, F32, "z2n")), B, D, _p(rstd), _p(dzn), _p(sums), float(inv_n), _p(out_scale),
+                                _p(dz1), _p(dz2), _stream()), "sa_bt_bwd_apply")
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_bf16=None):
     n = p.numel()

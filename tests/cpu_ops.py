@@ -131,3 +131,31 @@ def bt_loss_grad(c, alpha, lmbda, hsic, loss, G=None):
         g = 2 * lmbda * off
         g[eye] = 2 * alpha * (torch.diagonal(c) - 1)
         G.copy_(g)
+
+
+# ---- the fused loss-term entry points (csrc/bt_fused.hip), restated on the pieces above
+def bt_stats2(z1, z2, stats):
+    for v, z in enumerate((z1, z2)):
+        bn_colstats(z, stats[v, 0], stats[v, 1])
+
+
+def bt_corr(z1, z2, all_stats, eps, momentum, inv_n, mean, rstd, running_mean, running_var, z1n, z2n, c):
+    B = z1.shape[0]
+    for v, (z, zn) in enumerate(((z1, z1n), (z2, z2n))):       # bn(z1) then bn(z2): the running buffers see both, in this order
+        bn_finalize(all_stats[:, v], B, eps, momentum, mean[v], rstd[v], running_mean, running_var)
+        zn.copy_(_xhat(z, mean[v], rstd[v]))
+    c.copy_(inv_n * (z1n.t() @ z2n))
+
+
+def bt_bwd_products(z1n, z2n, G, inv_n, dzn, sums):
+    dzn[0].copy_(inv_n * (z2n @ G.t()))
+    dzn[1].copy_(inv_n * (z1n @ G))
+    for v, zn in enumerate((z1n, z2n)):
+        sums[v, 0].copy_(dzn[v].sum(0))
+        sums[v, 1].copy_((dzn[v] * zn).sum(0))
+
+
+def bt_bwd_apply(z1n, z2n, rstd, dzn, sums, inv_n, out_scale, dz1, dz2):
+    for v, (zn, dz) in enumerate(((z1n, dz1), (z2n, dz2))):
+        d = rstd[v] * (dzn[v] - sums[v, 0] * inv_n - zn * sums[v, 1] * inv_n)
+        dz.copy_(d * out_scale if out_scale is not None else d)
