@@ -199,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     stage_tile<B_KM, 8, HID>(rb, buf + 3 * TILE_BYTES, p.ldb, n0 + 128, k0, wave, lane);
   };
 
+  if (p.stagger & 4) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }     // (see gemm256_persist_kernel; not the default here: no gain measured)
   stage_all(smem, kt0 * BK);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -407,6 +408,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 
   int t = lid;
   if (t >= ntiles) return;
+  // static priority for the second-dispatched wave row (waves 4..7): both at priority 0, the older waves win every issue arbitration and
+  // the younger ones' MFMA segments take twice as long (cycle stamps of scripts/microbench/gemm_dephase_prof.hip: 2 300 - 2 800 against
+  // 1 300 cycles); MI355X_MICROARCH.md, "Two waves per SIMD", item 4
+  // -- measured (scripts/bench_gemm.py, A/B/A/B on one box): qkv forward 251-259 -> 240-241 us, fc1 forward 401-412 -> 384-386,
+  // fc2 dgrad 378-380 -> 357-360, proj dgrad 76-79 -> 71.5; default on (SA_GEMM_STAGGER bit 1)
+  if (p.stagger & 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
   int m0, n0;
   coords(t, m0, n0);
   stage_all(smem, m0, n0, 0);
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
       const bool more = kt + 1 < ksteps;
       // the second wave row requests its share of the next K-tile mid-step instead of at the top: halves the burst that blocks
       // every wave on the memory pipe's issue queue right after the barrier (measured 2-4 % on the forward shapes)
-      const bool late = p.stagger && wr == 1;
+      const bool late = (p.stagger & 1) && wr == 1;
       if (!late) {
         if (more) stage_all(smem + (cur ^ 1) * BUF, m0, n0, (kt + 1) * BK);
         else if (has_next) stage_all(smem + (cur ^ 1) * BUF, m0n, n0n, 0);
@@ -1123,7 +1130,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   static const char* rp_env = getenv("SA_GEMM_RING_PHASE");
   p.ring_phase = (rp_env && rp_env[0] == '0') ? 0 : 1;   // default on: 3-8 % on the dgrad shapes (SA_GEMM_RING_PHASE=0: uniform trickle)
   static const char* stg_env = getenv("SA_GEMM_STAGGER");
-  p.stagger = (stg_env && stg_env[0] == '0') ? 0 : 1;   // default on: measured 2-4 % on the forward shapes, 12-14 % on split-K wgrad (SA_GEMM_STAGGER=0 disables)
+  p.stagger = stg_env ? atoi(stg_env) : 3;              // bit 0: late requests of wave row 1; bit 1: priority 1 for wave row 1 in the persistent kernel; bit 2: the same in the split-K 256^2 kernel (experiment)   // default on: measured 2-4 % on the forward shapes, 12-14 % on split-K wgrad (SA_GEMM_STAGGER=0 disables)
   static const char* gm256_env = getenv("SA_GEMM_GM256");
   p.gm256 = gm256_env ? atoi(gm256_env) : 4;
   if (p.gm256 < 1) p.gm256 = 1;
