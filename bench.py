@@ -39,7 +39,7 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md: 6.29 TB/s meas
 
 
 def source_sha():
-    """Hash of the GEMM kernel sources: profiles/r03_gemm_traffic.json (HBM bytes of the GEMM launches) carries the hash it was collected
+    """Hash of the GEMM kernel sources: profiles/rNN_gemm_traffic.json (HBM bytes of the GEMM launches) carries the hash it was collected
     at and is ignored when stale."""
     import hashlib
     h = hashlib.sha256()
@@ -306,16 +306,18 @@ def main():
         d_ms, d_fl, d_nb, d_n = by_kernel[dom]
         d_tflops = d_fl / (d_ms * 1e-3) / 1e12
         traffic, traffic_note = None, "no PMC summary for this workload"
-        tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
+        tpath = tfiles[-1] if tfiles else ""                        # the newest round's PMC summary
         if os.path.exists(tpath) and B == bpg:
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same command (scripts/profile_round.sh), per
             # workload, valid only for the kernel sources it was collected with
             tj = json.load(open(tpath))
             if tj.get("source_sha") != source_sha():
-                traffic_note = "profiles/r03_gemm_traffic.json is stale (kernel sources changed since it was collected): ignored"
+                traffic_note = f"profiles/{os.path.basename(tpath)} is stale (kernel sources changed since it was collected): ignored"
             elif args.workload in tj.get("workloads", {}):
                 traffic = tj["workloads"][args.workload].get("per_kernel", {}).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of this command, profiles/r03_gemm_traffic.json"
+                traffic_note = f"rocprofv3 PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of this command, profiles/{os.path.basename(tpath)}"
         n_tok = (64 // 16) * (frames // 16) + 1
         exec_gf = executed_gflop_per_clip(model_type, mode, n_tok)
         hbm_kernels = {}
@@ -345,9 +347,20 @@ def main():
                        "dist_world": sdist.get_world_size(), "dist_backend": dist_backend, "rccl_version": rccl_version,
                        "launcher": "torch.distributed.run (self-launched child)" if os.environ.get("TORCHELASTIC_RUN_ID") is not None
                        and os.environ.get("SA_BENCH_PARENT") else ("torch.distributed.run" if "RANK" in os.environ else "single process")},
-            "roofline": {"bound": "mfma", "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
-                         "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_note": traffic_note,
+            # which bound applies: the kernel's arithmetic intensity against the ridge (2 500 TFLOP/s / 8 TB/s = 312 flop/B).  ViT-B's GEMMs sit
+            # above it (MFMA-bound); ViT-T's (d = 192: three K-tiles per output tile, weight gradients that read 245 MB for 38 GFLOP)
+            # far below, so their roofline is HBM and `frac` is the fraction of 8 TB/s the algorithmic bytes move at
+            "roofline": ({"bound": "mfma", "achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4)} if d_fl / max(d_nb, 1.0) >= PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS else
+                         {"bound": "hbm", "achieved": round(d_nb / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(d_nb / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}) | {
+                         "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
+                         "intensity_flop_per_byte": round(d_fl / max(d_nb, 1.0), 1), "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
+                         "mfma": {"achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4)},
+                         "hbm": {"achieved": round(d_nb / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(d_nb / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "pmc_achieved": round(traffic / (d_ms / d_n * 1e-3) / 1e9, 1) if traffic else None},
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_note": traffic_note,
                          "algorithmic_flop_per_launch": round(d_fl / d_n), "algorithmic_bytes_per_launch": round(d_nb / d_n),
                          "launches": d_n, "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
                          "share_of_step": round((d_ms / psteps) / (dt / args.steps * 1e3), 4),
@@ -355,8 +368,10 @@ def main():
                                    "after the timed region (the timed region itself carries no events: 2 x 160 of them per step cost 5 % of it)",
                          "all_gemm": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": len(prof),
                                       "share_of_step": round((gemm_ms / psteps) / (dt / args.steps * 1e3), 4),
+                                      "hbm_gbs_algorithmic": round(sum(v[2] for v in by_kernel.values()) / (gemm_ms * 1e-3) / 1e9, 1) if gemm_ms > 0 else None,
                                       "by_kernel": {k: {"tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1), "launches": v[3],
-                                                        "avg_launch_us": round(v[0] * 1e3 / v[3], 2)} for k, v in by_kernel.items() if v[0] > 0},
+                                                        "avg_launch_us": round(v[0] * 1e3 / v[3], 2),
+                                                        "hbm_gbs_algorithmic": round(v[2] / (v[0] * 1e-3) / 1e9, 1)} for k, v in by_kernel.items() if v[0] > 0},
                                       "by_layout_tflops": {k: round(f / (ms * 1e-3) / 1e12, 1) for k, (ms, f) in by_kind.items() if ms > 0}},
                          "hbm_kernels": hbm_kernels,
                          "whole_step_tflops_algorithmic": round(clips_per_s / world * GF_PER_CLIP[args.workload] / 1e3, 2),

@@ -1,7 +1,7 @@
 """How much do first-step gradients of the golden 'step' fixtures move when only the matmul operands are rounded to
 bf16 (CPU autocast), everything else fp32?  Sets the expectation for the HIP path's bf16 error on these fixtures."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import step as ostep, heads
 

@@ -1,6 +1,6 @@
 """Diagnostic: isolate where the byol-mode gradient error arises (run on the GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ssl_audio_amd import model, hyperparameters as hp
 from ssl_audio_amd.loss import BarlowTwinsLoss

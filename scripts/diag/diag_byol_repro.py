@@ -3,7 +3,7 @@ largest difference of the flat weights / Adam moments / gradients between the tw
 summation-order noise (atomic bias-gradient column sums); the question is how fast a step amplifies them (AdamW normalises
 noise-level gradients to +-lr steps) as opposed to a sudden jump (which would be a race)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ssl_audio_amd import hyperparameters as hp
 from ssl_audio_amd.train import BarlowTwinsTrainer

@@ -1,6 +1,6 @@
 """Diagnostic: is sa_layernorm_bwd bit-reproducible launch to launch (same inputs, fresh outputs)?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ssl_audio_amd import ops
 dev = "cuda"

@@ -1,6 +1,6 @@
 """Diagnostic: does the device-side non-finite gate keep AdamW from touching the weights?  (python scripts/diag_nan_gate.py)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ssl_audio_amd import ops, hyperparameters as hp
 from ssl_audio_amd.train import BarlowTwinsTrainer

@@ -1,13 +1,14 @@
 #!/bin/bash
-# One GPU-box session that refreshes the measured artefacts of the round under gpurun_out/r03/ (copied into profiles/ afterwards):
+# One GPU-box session that refreshes the measured artefacts of the round under gpurun_out/<round>/ (copied into profiles/ afterwards):
 #   per workload: rocprofv3 kernel stats of the bench, HBM traffic of its GEMM launches (PMC, separate FETCH_SIZE / WRITE_SIZE passes,
 #   stamped with the kernel-source hash) and the bench line (which embeds that traffic); for the headline workload also the per-kernel
 #   PMC of the GEMM families, the per-block GEMM table, the hipBLASLt bar and the attention table.
 #   usage: bash scripts/profile_round.sh [workload ...]        (default: all four)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03; mkdir -p $O
+R=${SA_ROUND:-r04}                      # file-name prefix of the round's artefacts (profiles/${R}_*)
+O=gpurun_out/$R; mkdir -p $O
 WL=${@:-vit_base_bt_10s vit_tiny_bt_10s vit_base_byol_10s vit_large_mae_10s}
-if [ $# -eq 0 ]; then rm -f $O/gemm_traffic.json; else cp profiles/r03_gemm_traffic.json $O/gemm_traffic.json; fi   # named workloads: refresh their entries only
+if [ $# -eq 0 ]; then rm -f $O/gemm_traffic.json; else cp profiles/${R}_gemm_traffic.json $O/gemm_traffic.json; fi   # named workloads: refresh their entries only
 for w in $WL; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no_cpu_baseline > $O/ktrace_$w.log 2>&1 || exit 1
   cp $(ls $O/ktrace_$w/*/*kernel_stats.csv | head -1) $O/bench_${w}_kernel_stats.csv 2>/dev/null
@@ -20,7 +21,7 @@ for w in $WL; do
   python3 scripts/traffic_summary.py gpurun_out/traffic $O/gemm_traffic.json $w > $O/gemm_traffic_summary_$w.txt 2>&1
   rm -rf gpurun_out/traffic
   echo "traffic $w done"; cut -c1-300 $O/gemm_traffic_summary_$w.txt
-  cp $O/gemm_traffic.json profiles/r03_gemm_traffic.json   # (the box-local copy: the bench line below embeds the traffic of THIS tree)
+  cp $O/gemm_traffic.json profiles/${R}_gemm_traffic.json   # (the box-local copy: the bench line below embeds the traffic of THIS tree)
   if [ $w = vit_base_bt_10s ]; then
     python3 bench.py --workload $w --steps 20 --warmup 5 > $O/bench_${w}_line.json 2> $O/bench_$w.err || exit 1
   else
@@ -31,10 +32,10 @@ done
 case " $WL " in *" vit_base_bt_10s "*) ;; *) exit 0;; esac
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM"; do
   n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_r03/$n -- python3 scripts/bench_gemm.py "N" 2 > $O/pmc_$n.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$R/$n -- python3 scripts/bench_gemm.py "N" 2 > $O/pmc_$n.log 2>&1 || exit 1
 done
-python3 scripts/pmc_summary.py gpurun_out/pmc_r03 > $O/gemm_pmc.txt 2>&1
-rm -rf gpurun_out/pmc_r03
+python3 scripts/pmc_summary.py gpurun_out/pmc_$R > $O/gemm_pmc.txt 2>&1
+rm -rf gpurun_out/pmc_$R
 echo "pmc done"
 python3 scripts/bench_gemm.py > $O/bench_gemm_block.txt 2>&1
 python3 scripts/bench_gemm_torch.py > $O/bench_gemm_hipblaslt.txt 2>&1

@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libssl_audio_hip.so")
+LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(_HERE, "csrc", "libssl_audio_hip.so")     # (SA_HIP_LIB: A/B builds of the library)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ssl_audio_hip.h")
 
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
