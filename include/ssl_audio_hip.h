@@ -265,14 +265,15 @@ int sa_mae_unshuffle_fwd(const float* x, int32_t keep, const float* mask_token, 
 int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32_t* ids_restore, int32_t B, int32_t L, int32_t d, float* dx,
                          float* dmask_token, void* stream);
 
-/* MAE reconstruction loss (forward_loss + patchify, models/mae.py:437-453, :282-293; one input channel, norm_pix_loss off):
- * loss = sum_l mask * mean_p (pred - patchify(img))^2 / sum mask.  acc2 = {numerator, sum mask} (kept for the backward);
+/* MAE reconstruction loss (forward_loss + patchify, models/mae.py:437-453, :282-293; one input channel):
+ * loss = sum_l mask * mean_p (pred - target)^2 / sum mask, target = patchify(img), with norm_pix != 0 normalised per patch
+ * ((t - mean) / sqrt(var + 1e-6), unbiased variance: models/mae.py:443-446; ABI v5).  acc2 = {numerator, sum mask} (kept for the backward);
  * bwd: dpred = gscale[0] * 2 * mask * (pred - target) / (P * sum mask).  pred / dpred are [B][pred_row0 + L][P] with
  * pred_seq_stride elements per clip: pred_row0 = 1 reads decoder_pred's output in place (its CLS row gets gradient 0). */
 int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
-                          float* acc2, float* loss, void* stream);
+                          int32_t norm_pix, float* acc2, float* loss, void* stream);
 int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
-                          int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream);
+                          int32_t F, int32_t T, int32_t ph, int32_t pw, int32_t norm_pix, float* dpred, void* stream);
 /* loss[0] = acc2[0] / acc2[1] again, after acc2 was summed over data-parallel ranks (global masked mean: what one process computes
  * on the global batch, models/mae.py:451-452). */
 int sa_mae_recon_loss_finalize(const float* acc2, float* loss, void* stream);

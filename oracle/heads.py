@@ -47,7 +47,23 @@ def mlp_bn_relu(x, w0, g, b, w1, ncrops):
 
 
 def head_forward(x, sd, ncrops=2, prefix="projector."):
-    return mlp_bn_relu(x, sd[prefix + "0.weight"], sd[prefix + "1.weight"], sd[prefix + "1.bias"], sd[prefix + "3.weight"], ncrops)
+    """BarlowTwinsHead.forward (model.py:25-31) for any `projector_n_hidden_layers` (model.py:16-22: n x [Linear, BatchNorm1d, ReLU] +
+    [Linear], keys projector.{3i}.weight / projector.{3i+1}.{weight,bias}); returns (z, BatchNorm statistics in call order)."""
+    n_hidden = 0
+    while f"{prefix}{3 * n_hidden + 1}.weight" in sd:
+        n_hidden += 1
+    if n_hidden == 1:
+        return mlp_bn_relu(x, sd[prefix + "0.weight"], sd[prefix + "1.weight"], sd[prefix + "1.bias"], sd[prefix + "3.weight"], ncrops)
+    outs, stats = [], []
+    for xc in x.chunk(ncrops):
+        h = xc
+        for i in range(n_hidden):
+            h = R.qb(F.linear(R.qf(h), R.qw(sd[f"{prefix}{3 * i}.weight"])))
+            hn, mu, var = batchnorm_train(h, sd[f"{prefix}{3 * i + 1}.weight"], sd[f"{prefix}{3 * i + 1}.bias"])
+            stats.append((mu, var, h.shape[0]))
+            h = F.relu(hn)
+        outs.append(R.qb(F.linear(R.qf(h), R.qw(sd[f"{prefix}{3 * n_hidden}.weight"]))))
+    return torch.cat(outs), stats
 
 
 def predictor_forward(x, sd, ncrops=2):

@@ -223,22 +223,39 @@ def masking_from_noise(x, noise=None, mask=None, mask_ratio=0.0):
     return x_masked, torch.gather(m, 1, ids_restore), ids_restore
 
 
-def prepare_tokens(x, p, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None):
+def learned_pos_table(pos_embed, grid, freq_bins, frames, patch=(16, 16)):
+    """interpolate_pos_encoding with `use_learned_pos_embd` (models/mae.py:367-392): the trained table itself only when the patch count
+    matches AND the input is square (`w == h`, :372), otherwise its bicubic resampling (scale factors (n + 0.1) / grid) -- in torch, so
+    that autograd carries the table's gradient through it."""
+    gh, gw = grid
+    nf, nt = freq_bins // patch[0], frames // patch[1]
+    if nf * nt == gh * gw and freq_bins == frames:
+        return pos_embed
+    pp = pos_embed[:, 1:].reshape(1, gh, gw, -1).permute(0, 3, 1, 2)
+    pp = F.interpolate(pp, scale_factor=((nf + 0.1) / gh, (nt + 0.1) / gw), mode="bicubic")
+    assert tuple(pp.shape[-2:]) == (nf, nt)
+    return torch.cat((pos_embed[:, :1], pp.permute(0, 2, 3, 1).reshape(1, nf * nt, -1)), dim=1)
+
+
+def prepare_tokens(x, p, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None, learned_pos=False):
     """prepare_tokens (models/mae.py:349-365).  `patch` = patch size, required for a conv stem (a PatchEmbed carries it in its kernel)."""
     B, _, Fb, T = x.shape
     if patch is None:
         patch = tuple(p["patch_embed.proj.weight"].shape[-2:])
     tok = patch_embed(x, p, patch, bn_stats)
-    pos = torch.from_numpy(interpolate_pos_embed(p["pos_embed"].detach().numpy(), grid, Fb, T, tuple(patch))).to(x.dtype)
+    if learned_pos:
+        pos = learned_pos_table(p["pos_embed"], grid, Fb, T, tuple(patch))
+    else:
+        pos = torch.from_numpy(interpolate_pos_embed(p["pos_embed"].detach().numpy(), grid, Fb, T, tuple(patch))).to(x.dtype)
     tok = tok + pos[:, 1:]
     tok, m, ids_restore = masking_from_noise(tok, noise, mask, mask_ratio)
     cls = (p["cls_token"] + p["pos_embed"][:, :1]).expand(B, -1, -1)
     return torch.cat((cls, tok), dim=1), m, ids_restore
 
 
-def forward_encoder(x, p, num_heads, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None):
+def forward_encoder(x, p, num_heads, grid, noise=None, mask=None, mask_ratio=0.0, patch=None, bn_stats=None, learned_pos=False):
     """forward_encoder (models/mae.py:394-400)."""
-    tok, m, ids_restore = prepare_tokens(x, p, grid, noise, mask, mask_ratio, patch, bn_stats)
+    tok, m, ids_restore = prepare_tokens(x, p, grid, noise, mask, mask_ratio, patch, bn_stats, learned_pos)
     for i in range(infer_arch(p)):
         tok = block(tok, p, f"blocks.{i}.", num_heads)
     C = tok.shape[-1]
@@ -267,16 +284,19 @@ def forward_decoder(x, ids_restore, p, dec_heads):
     return R.qb(F.linear(R.qf(x), R.qw(p["decoder_pred.weight"]), p["decoder_pred.bias"]))[:, 1:]
 
 
-def recon_loss(imgs, pred, mask, grid):
-    """forward_loss (models/mae.py:437-453), norm_pix_loss=False."""
-    loss = ((pred - patchify(imgs, grid)) ** 2).mean(dim=-1)
+def recon_loss(imgs, pred, mask, grid, norm_pix=False):
+    """forward_loss (models/mae.py:437-453); norm_pix: targets normalised per patch with the unbiased variance (:443-446)."""
+    target = patchify(imgs, grid)
+    if norm_pix:
+        target = (target - target.mean(dim=-1, keepdim=True)) / (target.var(dim=-1, keepdim=True) + 1.e-6) ** .5
+    loss = ((pred - target) ** 2).mean(dim=-1)
     return (loss * mask).sum() / mask.sum()
 
 
 def forward(x, p, num_heads, grid, mean_pool=False, noise=None, mask=None, mask_ratio=0.0,
-            masked_recon=False, dec_heads=6, patch=None, bn_stats=None):
+            masked_recon=False, dec_heads=6, patch=None, bn_stats=None, learned_pos=False):
     """MaskedAutoencoderViT.forward (models/mae.py:455-469)."""
-    enc, m, ids_restore = forward_encoder(x, p, num_heads, grid, noise, mask, mask_ratio, patch, bn_stats)
+    enc, m, ids_restore = forward_encoder(x, p, num_heads, grid, noise, mask, mask_ratio, patch, bn_stats, learned_pos)
     latent = enc[:, 1:].mean(dim=1) if mean_pool else enc[:, 0]
     if masked_recon:
         pred = forward_decoder(enc, ids_restore, p, dec_heads)

@@ -56,8 +56,8 @@ _SIGNATURES = {
     "sa_mean_tokens_bwd": [P, I32, I32, I32, P, P],
     "sa_mae_unshuffle_fwd": [P, I32, P, P, P, I32, I32, I32, P, P],
     "sa_mae_unshuffle_bwd": [P, I32, P, I32, I32, I32, P, P, P],
-    "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, P, P, P],
-    "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, P, P],
+    "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, I32, P, P, P],
+    "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, I32, P, P],
     "sa_mae_recon_loss_finalize": [P, P, P],
     "sa_maxpool3s2_fwd": [P, I32, I32, I32, I32, P, P, P, P],
     "sa_maxpool3s2_bwd": [P, P, I32, I32, I32, I32, P, P],

@@ -158,10 +158,36 @@ __global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __r
 
 // ---- MAE reconstruction loss (models/mae.py:437-453, patchify :282-293; one input channel):
 // target[b][l][py*pw + px] = img[b][gy*ph + py][gx*pw + px], l = gy*gw + gx;  loss = sum_l mask * mean_p (pred - target)^2 / sum mask.
-// Pass 1: one wave per (b, l) row -> acc[0] += mask * mean_p (.)^2, acc[1] += mask.   Pass 2 (finalize): loss = acc[0] / acc[1].
+// norm_pix (models/mae.py:443-446): target <- (target - mean_p target) / sqrt(var_p target + 1e-6), var unbiased (torch.var's default).
+// Pass 1: one wave per (b, l) row; every block leaves {sum mask * mean_p (.)^2, sum mask} in a device global and a one-wave launch adds the
+// blocks in block order (no float atomics: bit-reproducible) -> acc[0], acc[1].   Pass 2 (finalize): loss = acc[0] / acc[1].
+__device__ float mae_loss_partials[2 * 2048];
+
+// the patch's pixels of this lane (p = lane, lane + 64, ...) and, with norm_pix, its mean and 1 / sqrt(var + 1e-6) over the whole patch
+template <int MAXP>
+__device__ __forceinline__ void patch_pixels(const float* ip, int T, int pw, int P, int lane, int norm_pix, float (&t)[MAXP], float& mu, float& rs) {
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    const int p = lane + 64 * q;
+    t[q] = p < P ? ip[(int64_t)(p / pw) * T + (p % pw)] : 0.f;
+  }
+  mu = 0.f; rs = 1.f;
+  if (norm_pix) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) s += t[q];
+    mu = wave_sum(s) / (float)P;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) { const float d = (lane + 64 * q < P) ? t[q] - mu : 0.f; v += d * d; }
+    rs = rsqrtf(wave_sum(v) / (float)(P - 1) + 1.e-6f);
+  }
+}
+constexpr int MAE_MAXP = 8;      // patches of up to 512 pixels (16 x 16 = 256, 64 x 2 = 128, 16 x 8 = 128, 8 x 8 = 64)
+
 __global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restrict__ pred, int64_t pred_seq_stride, int pred_row0,
                                                             const float* __restrict__ img, const float* __restrict__ mask,
-                                                            int B, int F, int T, int ph, int pw, float* __restrict__ acc) {
+                                                            int B, int F, int T, int ph, int pw, int norm_pix) {
   __shared__ float red[8];
   const int gh = F / ph, gw = T / pw, L = gh * gw, P = ph * pw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,11 +200,16 @@ __global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restr
     const int gy = l / gw, gx = l % gw;
     const float* ip = img + ((int64_t)b * F + (int64_t)gy * ph) * T + (int64_t)gx * pw;
     const float* pr = pred + (int64_t)b * pred_seq_stride + (int64_t)(pred_row0 + l) * P;
+    float t[MAE_MAXP], mu, rs;
+    patch_pixels<MAE_MAXP>(ip, T, pw, P, lane, norm_pix, t, mu, rs);
     float s = 0.f;
-    for (int p = lane; p < P; p += 64) {
-      const float t = ip[(int64_t)(p / pw) * T + (p % pw)];
-      const float e = pr[p] - t;
-      s += e * e;
+#pragma unroll
+    for (int q = 0; q < MAE_MAXP; ++q) {
+      const int p = lane + 64 * q;
+      if (p < P) {
+        const float e = pr[p] - (t[q] - mu) * rs;
+        s += e * e;
+      }
     }
     s = wave_sum(s);
     if (lane == 0) num += m * s / (float)P;
@@ -187,8 +218,22 @@ __global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restr
   if (lane == 0) { red[wave] = num; red[4 + wave] = den; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(acc + 0, red[0] + red[1] + red[2] + red[3]);
-    atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+    mae_loss_partials[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    mae_loss_partials[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+__global__ __launch_bounds__(64) void mae_loss_sum_kernel(int nblocks, float* __restrict__ acc, float* __restrict__ loss) {
+  __shared__ float lanes[2][64];
+  float a = 0.f, b = 0.f;
+  for (int k = threadIdx.x; k < nblocks; k += 64) { a += mae_loss_partials[2 * k]; b += mae_loss_partials[2 * k + 1]; }
+  lanes[0][threadIdx.x] = a; lanes[1][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int l = 0; l < 64; ++l) { ta += lanes[0][l]; tb += lanes[1][l]; }
+    acc[0] = ta; acc[1] = tb;
+    if (loss) loss[0] = ta / tb;
   }
 }
 
@@ -196,28 +241,32 @@ __global__ void mae_loss_finalize_kernel(const float* __restrict__ acc, float* _
 
 // dpred[b][row0 + l][p] = gscale * 2 * mask * (pred - target) / (P * sum mask), rows below row0 (the CLS prediction) get 0;
 // pred / dpred share the [B][row0 + L][P] layout (seq_stride elements per clip).  gscale = upstream gradient (device scalar).
-__global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, int64_t seq_stride, int row0, const float* __restrict__ img,
-                                    const float* __restrict__ mask, const float* __restrict__ acc, const float* __restrict__ gscale, int B,
-                                    int F, int T, int ph, int pw, float* __restrict__ dpred) {
+// One wave per (b, r) row (the per-patch statistics of norm_pix are a wave reduction).
+__global__ __launch_bounds__(256) void mae_loss_bwd_kernel(const float* __restrict__ pred, int64_t seq_stride, int row0, const float* __restrict__ img,
+                                                           const float* __restrict__ mask, const float* __restrict__ acc,
+                                                           const float* __restrict__ gscale, int B, int F, int T, int ph, int pw, int norm_pix,
+                                                           float* __restrict__ dpred) {
   const int gh = F / ph, gw = T / pw, L = gh * gw, P = ph * pw;
-  const int64_t n = (int64_t)B * (row0 + L) * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float k = gscale[0] * 2.f / ((float)P * acc[1]);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int p = (int)(i % P);
-    const int64_t br = i / P;
+  for (int64_t br = (int64_t)blockIdx.x * 4 + wave; br < (int64_t)B * (row0 + L); br += (int64_t)gridDim.x * 4) {
     const int r = (int)(br % (row0 + L)), b = (int)(br / (row0 + L));
-    float v = 0.f;
-    const int64_t off = (int64_t)b * seq_stride + (int64_t)r * P + p;
-    if (r >= row0) {
-      const int l = r - row0;
-      const float m = mask[(int64_t)b * L + l];
-      if (m != 0.f) {
-        const int gy = l / gw, gx = l % gw;
-        const float t = img[((int64_t)b * F + (int64_t)gy * ph + p / pw) * T + (int64_t)gx * pw + (p % pw)];
-        v = k * m * (pred[off] - t);
-      }
+    const int64_t off = (int64_t)b * seq_stride + (int64_t)r * P;
+    const int l = r - row0;
+    const float m = r >= row0 ? mask[(int64_t)b * L + l] : 0.f;        // wave-uniform
+    if (m == 0.f) {
+      for (int p = lane; p < P; p += 64) dpred[off + p] = 0.f;
+      continue;
     }
-    dpred[off] = v;
+    const int gy = l / gw, gx = l % gw;
+    const float* ip = img + ((int64_t)b * F + (int64_t)gy * ph) * T + (int64_t)gx * pw;
+    float t[MAE_MAXP], mu, rs;
+    patch_pixels<MAE_MAXP>(ip, T, pw, P, lane, norm_pix, t, mu, rs);
+#pragma unroll
+    for (int q = 0; q < MAE_MAXP; ++q) {
+      const int p = lane + 64 * q;
+      if (p < P) dpred[off + p] = k * m * (pred[off + p] - (t[q] - mu) * rs);
+    }
   }
 }
 
@@ -320,19 +369,17 @@ extern "C" int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32
 }
 
 extern "C" int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
-                                     float* acc2, float* loss, void* stream) {
+                                     int32_t norm_pix, float* acc2, float* loss, void* stream) {
   SA_CHECK_ARG(pred && img && mask && acc2 && loss && B > 0 && ph > 0 && pw > 0 && F >= ph && T >= pw && F % ph == 0 && T % pw == 0 &&
                    pred_row0 >= 0 && pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw,
                "sa_mae_recon_loss_fwd: bad args (F, T must be multiples of the patch size; pred rows must fit the clip stride)");
-  if (hipMemsetAsync(acc2, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    sa_set_error("sa_mae_recon_loss_fwd: memset failed");
-    return 2;
-  }
+  SA_CHECK_ARG(ph * pw <= 64 * MAE_MAXP && (!norm_pix || ph * pw > 1), "sa_mae_recon_loss_fwd: patches of at most %d pixels", 64 * MAE_MAXP);
   const int64_t rows = (int64_t)B * (F / ph) * (T / pw);
   int grid = (int)((rows + 3) / 4);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(mae_loss_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, B, F, T, ph, pw, acc2);
-  hipLaunchKernelGGL(mae_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc2, loss);
+  hipLaunchKernelGGL(mae_loss_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, B, F, T, ph, pw,
+                     norm_pix);
+  hipLaunchKernelGGL(mae_loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, acc2, loss);
   SA_LAUNCH_CHECK("sa_mae_recon_loss_fwd");
   return 0;
 }
@@ -345,12 +392,15 @@ extern "C" int sa_mae_recon_loss_finalize(const float* acc2, float* loss, void* 
 }
 
 extern "C" int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
-                                     int32_t F, int32_t T, int32_t ph, int32_t pw, float* dpred, void* stream) {
+                                     int32_t F, int32_t T, int32_t ph, int32_t pw, int32_t norm_pix, float* dpred, void* stream) {
   SA_CHECK_ARG(pred && img && mask && acc2 && gscale && dpred && B > 0 && ph > 0 && pw > 0 && F % ph == 0 && T % pw == 0 && pred_row0 >= 0 &&
-                   pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw, "sa_mae_recon_loss_bwd: bad args");
-  const int64_t n = (int64_t)B * (pred_row0 + (F / ph) * (T / pw)) * ph * pw;
-  hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, acc2,
-                     gscale, B, F, T, ph, pw, dpred);
+                   pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw && ph * pw <= 64 * MAE_MAXP,
+               "sa_mae_recon_loss_bwd: bad args");
+  const int64_t rows = (int64_t)B * (pred_row0 + (F / ph) * (T / pw));
+  int grid = (int)((rows + 3) / 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, acc2,
+                     gscale, B, F, T, ph, pw, norm_pix, dpred);
   SA_LAUNCH_CHECK("sa_mae_recon_loss_bwd");
   return 0;
 }

@@ -79,9 +79,9 @@ SCHEMAS = {
     "mean_tokens_bwd": ("sa_mean_tokens_bwd", "(Tensor dout, Tensor(a!) dy) -> ()"),
     "mae_unshuffle_fwd": ("sa_mae_unshuffle_fwd", "(Tensor x, Tensor mask_token, Tensor pos, Tensor ids_restore, Tensor(a!) out) -> ()"),
     "mae_unshuffle_bwd": ("sa_mae_unshuffle_bwd", "(Tensor dout, int keep, Tensor ids_restore, Tensor(a!) dx, Tensor(b!) dmask_token) -> ()"),
-    "mae_recon_loss_fwd": ("sa_mae_recon_loss_fwd", "(Tensor pred, int row0, Tensor img, Tensor mask, int ph, int pw, Tensor(a!) acc2, Tensor(b!)? loss) -> ()"),
+    "mae_recon_loss_fwd": ("sa_mae_recon_loss_fwd", "(Tensor pred, int row0, Tensor img, Tensor mask, int ph, int pw, Tensor(a!) acc2, Tensor(b!) loss, bool norm_pix=False) -> ()"),
     "mae_recon_loss_finalize": ("sa_mae_recon_loss_finalize", "(Tensor acc2, Tensor(a!) loss) -> ()"),
-    "mae_recon_loss_bwd": ("sa_mae_recon_loss_bwd", "(Tensor pred, int row0, Tensor img, Tensor mask, int ph, int pw, Tensor acc2, Tensor gscale, Tensor(a!) dpred) -> ()"),
+    "mae_recon_loss_bwd": ("sa_mae_recon_loss_bwd", "(Tensor pred, int row0, Tensor img, Tensor mask, int ph, int pw, Tensor acc2, Tensor gscale, Tensor(a!) dpred, bool norm_pix=False) -> ()"),
     "conv3x3_c1_fwd": ("sa_conv3x3_c1_fwd", "(Tensor x, Tensor w, Tensor? bias, int[] stride, Tensor(a!) y) -> ()"),
     "conv3x3_c1_wgrad": ("sa_conv3x3_c1_wgrad", "(Tensor x, Tensor dy16, int[] stride, Tensor(a!) dw, Tensor(b!)? dbias=None) -> ()"),
     "im2col3x3": ("sa_im2col3x3_bf16", "(Tensor x16, int B, int H, int W, int C, int[] stride, Tensor(a!) out) -> ()"),

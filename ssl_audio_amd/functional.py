@@ -17,11 +17,13 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 class TokensFn(torch.autograd.Function):
     """imgs [S,1,F,T] -> tokens [S, 1+L(or keep), d] fp32 (prepare_tokens, models/mae.py:349-365).
-    Patch projection and positional table are frozen in the reference (models/mae.py:190-192,202), so the only
-    gradient is the CLS token's.  ids_keep [S, keep] int32 (or None) applies random_masking's keep-gather."""
+    The patch projection is frozen in the reference (models/mae.py:190-192) and so is the sin-cos positional table (:202): the
+    gradients are the CLS token's and, with `--use_learned_pos_embd` (:198-199; `pos_param` = the live nn.Parameter, used at its
+    own grid), the positional table's: dpos[n] = sum over the sequences of dtok[s][n] (kept rows only under random masking).
+    ids_keep [S, keep] int32 (or None) applies random_masking's keep-gather."""
 
     @staticmethod
-    def forward(ctx, imgs, cls_token, w_pe, b_pe, pos, ids_keep):
+    def forward(ctx, imgs, cls_token, w_pe, b_pe, pos, ids_keep, pos_param=None, pos_A=None):
         S, _, F_, T_ = imgs.shape
         d = w_pe.shape[0]
         ph, pw = w_pe.shape[-2:]
@@ -30,10 +32,11 @@ class TokensFn(torch.autograd.Function):
         patches = torch.empty(S * L, ph * pw, dtype=BF16, device=dev)
         ops.patchify_bf16(imgs.contiguous(), patches, ph, pw)
         tok = torch.empty(S, 1 + L, d, device=dev)
-        pos2 = pos.reshape(1 + L, d)
+        pos2 = pos.detach().reshape(1 + L, d)
         ops.gemm(patches, BF16_WEIGHTS.get(w_pe), bias=b_pe.detach(), residual=pos2[1:], res_mod=L, row_group=L,
                  out_f32=tok.view(S * (1 + L), d))
         ops.fill_cls(tok, S, (1 + L) * d, d, cls_token.detach().reshape(-1), pos2[0])
+        rows = None
         if ids_keep is not None:
             keep = ids_keep.shape[1]
             out = torch.empty(S, 1 + keep, d, device=dev)
@@ -42,18 +45,37 @@ class TokensFn(torch.autograd.Function):
             tok = out
         ctx.shape = tok.shape
         ctx.cls_param = cls_token
+        ctx.pos_param = pos_param if (pos_param is not None and pos_param.requires_grad) else None
+        ctx.rows, ctx.full, ctx.pos_A = rows, (S, 1 + L, d), pos_A
         return tok
 
     @staticmethod
     def backward(ctx, dtok):
         S, N, d = ctx.shape
-        dcls = None
+        dcls = dpos = None
+        dtok = dtok.contiguous()
         if ctx.needs_input_grad[1]:
-            dtok = dtok.contiguous()
             buf, ret = grad_target(ctx.cls_param)
             ops.cls_grad(dtok, S, N * d, d, buf.view(-1))
             dcls = ret
-        return None, dcls, None, None, None, None
+        if ctx.pos_param is not None:
+            buf, dpos = grad_target(ctx.pos_param)
+            full = dtok
+            if ctx.rows is not None:                 # masked: put the kept rows back at their token positions (zeros elsewhere) first
+                full = torch.zeros(ctx.full, device=dtok.device)
+                ops.scatter_add_rows(dtok, N * d, 0, ctx.rows, full, ctx.full[1] * d, 0, S, d)
+            nd = ctx.full[1] * d
+            if ctx.pos_A is None:
+                ops.cls_grad(full, S, nd, nd, buf.view(-1))      # column sums over the sequences, in a fixed order
+            else:                                                # resampled table: dP[0] = sum_s dtok[s][0], dP[1:] = A^T sum_s dtok[s][1:]
+                dsum = torch.zeros(ctx.full[1], d, device=dtok.device)
+                ops.cls_grad(full, S, nd, nd, dsum.view(-1))
+                b2 = buf.view(-1, d)
+                ops.axpy(b2[0], dsum[0])
+                dpatch = torch.empty(ctx.pos_A.shape[1], d, device=dtok.device)
+                ops.matmul_f32(ctx.pos_A, dsum[1:], dpatch, trans_a=True)
+                ops.axpy(b2[1:].reshape(-1), dpatch.view(-1))
+        return None, dcls, None, None, None, None, dpos, None
 
 
 class MaeUnshuffleFn(torch.autograd.Function):
@@ -92,27 +114,27 @@ class MaeReconLossFn(torch.autograd.Function):
     `pred` is decoder_pred's full output [B, row0 + L, P]; row0 = 1 skips its CLS row in place (models/mae.py:433)."""
 
     @staticmethod
-    def forward(ctx, pred, imgs, mask, ph, pw, row0):
+    def forward(ctx, pred, imgs, mask, ph, pw, row0, norm_pix=False):
         pred = pred.contiguous(); imgs = imgs.contiguous(); mask = mask.contiguous().float()
         if imgs.shape[1] != 1:
             raise ValueError("MaeReconLossFn: the audio path has one input channel")
         acc2 = torch.empty(2, device=pred.device)
         loss = torch.empty((), device=pred.device)
-        ops.mae_recon_loss_fwd(pred, row0, imgs, mask, ph, pw, acc2, loss.view(1))
+        ops.mae_recon_loss_fwd(pred, row0, imgs, mask, ph, pw, acc2, loss.view(1), norm_pix)
         if sdist.collectives_active():             # global masked mean: (sum of masked errors, mask count) summed over ranks
             sdist.all_reduce_sum_(acc2)
             ops.mae_recon_loss_finalize(acc2, loss.view(1))
         ctx.save_for_backward(pred, imgs, mask, acc2)
-        ctx.cfg = (ph, pw, row0)
+        ctx.cfg = (ph, pw, row0, norm_pix)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         pred, imgs, mask, acc2 = ctx.saved_tensors
-        ph, pw, row0 = ctx.cfg
+        ph, pw, row0, norm_pix = ctx.cfg
         dpred = torch.empty_like(pred)
-        ops.mae_recon_loss_bwd(pred, row0, imgs, mask, ph, pw, acc2, g.reshape(1).float().contiguous(), dpred)
-        return dpred, None, None, None, None, None
+        ops.mae_recon_loss_bwd(pred, row0, imgs, mask, ph, pw, acc2, g.reshape(1).float().contiguous(), dpred, norm_pix)
+        return dpred, None, None, None, None, None, None
 
 
 class MeanTokensFn(torch.autograd.Function):
@@ -233,6 +255,48 @@ class MlpBnReluFn(torch.autograd.Function):
             dx = torch.empty(B, w0.shape[1], device=dev)
             _gemm_f32_long_k(dh, BF16_WEIGHTS.get(w0), dx, b_kmajor=False)
         return dx, dw0, dgamma, dbeta, dw1, None, None
+
+
+class LinearBnReluFn(torch.autograd.Function):
+    """One hidden block Linear(nb) -> BN1d(train, affine) -> ReLU of a projector with `--projector_n_hidden_layers` > 1 (model.py:16-22):
+    the front part of MlpBnReluFn on its own, fp32 out (the next block casts its own GEMM operand)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, gamma, beta, running_mean, running_var):
+        B = x.shape[0]
+        dev = x.device
+        x16 = ops.cast_bf16(x.contiguous())
+        h = torch.empty(B, w0.shape[0], device=dev)
+        ops.gemm(x16, BF16_WEIGHTS.get(w0), out_f32=h)
+        mean, rstd = _bn_forward_stats(h, BN_EPS, running_mean, running_var)
+        a = torch.empty(B, w0.shape[0], device=dev)
+        ops.bn_apply(h, mean, rstd, gamma.detach(), beta.detach(), True, y_f32=a)
+        ctx.save_for_backward(x16, h, mean, rstd, w0, gamma, beta)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x16, h, mean, rstd, w0, gamma, beta = ctx.saved_tensors
+        B, Hd = h.shape
+        dev = h.device
+        W = sdist.get_world_size()
+        da = da.contiguous().float()
+        s = torch.empty(2, Hd, device=dev)
+        ops.bn_bwd_stats(da, h, mean, rstd, gamma, beta, True, s[0], s[1])
+        dgb, dgamma = grad_target(gamma)                    # local contributions (summed over ranks with the other grads)
+        dbb, dbeta = grad_target(beta)
+        ops.axpy(dbb, s[0])
+        ops.axpy(dgb, s[1])
+        sdist.all_reduce_sum_(s)
+        dh = torch.empty(B, Hd, dtype=BF16, device=dev)
+        ops.bn_bwd_apply(da, h, mean, rstd, gamma, beta, True, s[0], s[1], 1.0 / (B * W), dx_bf16=dh)
+        dw0b, dw0 = grad_target(w0)
+        _wgrad(dh, x16, dw0b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, w0.shape[1], device=dev)
+            _gemm_f32_long_k(dh, BF16_WEIGHTS.get(w0), dx, b_kmajor=False)
+        return dx, dw0, dgamma, dbeta, None, None
 
 
 class BTLossFn(torch.autograd.Function):

@@ -4,7 +4,8 @@ signature as the reference's models/mae.py:166-469, so checkpoints and call site
 The nn.Module tree below only *owns parameters* (identical names / shapes / init families as the reference);
 no submodule's forward is ever called.  Compute is the explicit HIP schedule in engine.py / functional.py.
 The `vitc_*` variants put the ConvStem (convstem.py) in place of the patch projection.
-Not provided (out of this path's scope): learned positional embedding, norm_pix_loss, forward_attn / forward_viz.
+Not provided (out of this path's scope): stochastic depth, forward_attn / forward_viz; the learned positional embedding is
+used at its own patch grid only (no gradient through the bicubic resampling of other widths).
 """
 from functools import partial
 
@@ -80,8 +81,10 @@ class MaskedAutoencoderViT(nn.Module):
                  block_cls=BlockKBiasZero, use_2d_dec_pos_embd=False,
                  drop_path_rate=0.):
         super().__init__()
-        if use_learned_pos_embd or norm_pix_loss or drop_path_rate:
-            raise NotImplementedError("learned pos-embed / norm_pix_loss / drop_path are not on the MI355X hot path")
+        if drop_path_rate:
+            raise NotImplementedError("stochastic depth (drop_path_rate > 0) is not on the MI355X hot path (the reference never sets it)")
+        if use_learned_pos_embd and conv_stem:
+            raise NotImplementedError("the learned positional embedding is implemented for the plain patch projection (not the ConvStem)")
         if in_chans != 1:
             raise NotImplementedError("audio spectrogram input only (in_chans=1)")
         if (embed_dim // num_heads) != 64 or (use_decoder and decoder_embed_dim // decoder_num_heads != 64):
@@ -99,7 +102,8 @@ class MaskedAutoencoderViT(nn.Module):
                 param.requires_grad = False
         total_patches = self.patch_embed.num_patches + 1
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.pos_embed = nn.Parameter(torch.zeros(1, total_patches, embed_dim), requires_grad=False)
+        # fixed sin-cos table, or trained (`--use_learned_pos_embd`, models/mae.py:198-202)
+        self.pos_embed = nn.Parameter(torch.zeros(1, total_patches, embed_dim), requires_grad=bool(use_learned_pos_embd))
         self.blocks = nn.ModuleList([block_cls(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
                                      for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
@@ -128,8 +132,11 @@ class MaskedAutoencoderViT(nn.Module):
 
     # ------------------------------------------------------------------ init (models/mae.py:242-279)
     def initialize_weights(self, use_2d_dec_pos_embd=False):
-        pos = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], self.grid_size())
-        self.pos_embed.data.copy_(torch.from_numpy(pos).float().unsqueeze(0))
+        if self.use_learned_pos_embd:
+            torch.nn.init.normal_(self.pos_embed, std=.02)              # models/mae.py:244-245
+        else:
+            pos = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], self.grid_size())
+            self.pos_embed.data.copy_(torch.from_numpy(pos).float().unsqueeze(0))
         if self.use_decoder:
             if use_2d_dec_pos_embd:
                 dpos = get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], self.grid_size())
@@ -155,6 +162,8 @@ class MaskedAutoencoderViT(nn.Module):
 
     # ------------------------------------------------------------------ positional table per input width (cached)
     def interpolate_pos_encoding(self, freq_bins, frames):
+        if self.use_learned_pos_embd:
+            return self._learned_pos(freq_bins, frames)[0]
         key = (freq_bins, frames, self.pos_embed.device, self.pos_embed._version)
         if key not in self._pos_cache:
             self._pos_cache.clear()
@@ -162,6 +171,26 @@ class MaskedAutoencoderViT(nn.Module):
                                            self.patch_size())
             self._pos_cache[key] = torch.from_numpy(pos).float().to(self.pos_embed.device).contiguous()
         return self._pos_cache[key]
+
+    def _learned_pos(self, freq_bins, frames):
+        """(`pos` [1, 1 + L, d], A) for the TRAINED table (`--use_learned_pos_embd`): read live every call (the optimiser's launches
+        rewrite it without touching `_version`), resampled by the reference's bicubic map whenever the input is not square
+        (models/mae.py:370-392: `w == h` is the only shortcut there) -- A [L, gh * gw] on the device, None for the identity."""
+        ph, pw = self.patch_size()
+        nf, nt = freq_bins // ph, frames // pw
+        gh, gw = self.grid_size()
+        if nf * nt == gh * gw and freq_bins == frames:
+            return self.pos_embed, None
+        key = ("A", nf, nt, self.pos_embed.device)
+        if key not in self._pos_cache:
+            from .pos_embed import interpolation_matrix
+            self._pos_cache[key] = torch.from_numpy(interpolation_matrix((gh, gw), nf, nt)).float().to(self.pos_embed.device).contiguous()
+        A = self._pos_cache[key]
+        table = self.pos_embed.detach()[0]
+        pos = torch.empty(1 + nf * nt, table.shape[1], device=table.device)
+        pos[0].copy_(table[0])
+        ops.matmul_f32(A, table[1:], pos[1:])
+        return pos.unsqueeze(0), A
 
     def patchify(self, imgs):
         ph, pw = self.patch_size()
@@ -194,7 +223,7 @@ class MaskedAutoencoderViT(nn.Module):
     def prepare_tokens(self, x, mask_ratio, noise=None):
         B, nc, w, h = x.shape
         L = (w // self.patch_size()[0]) * (h // self.patch_size()[1])
-        pos = self.interpolate_pos_encoding(w, h)
+        pos, pos_A = self._learned_pos(w, h) if self.use_learned_pos_embd else (self.interpolate_pos_encoding(w, h), None)
         no_mask = not isinstance(mask_ratio, (torch.Tensor, np.ndarray, list, tuple)) and mask_ratio == 0
         if no_mask:
             ids_keep, mask = None, torch.zeros([B, L], device=x.device)
@@ -204,7 +233,8 @@ class MaskedAutoencoderViT(nn.Module):
         if self.conv_stem:
             tok = ConvStemTokensFn.apply(x, self.cls_token, pos, ids_keep, self.patch_embed, *stem_flat_params(self.patch_embed))
         else:
-            tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep)
+            tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep,
+                                    self.pos_embed if self.use_learned_pos_embd else None, pos_A)
         return tok, mask, ids_restore
 
     def _run_blocks(self, tok, blocks, norm, heads, pool):
@@ -222,7 +252,8 @@ class MaskedAutoencoderViT(nn.Module):
 
     def forward_loss(self, imgs, pred, mask):
         ph, pw = self.patch_size()
-        return Fn.MaeReconLossFn.apply(pred, imgs, mask, ph, pw, pred.shape[1] - mask.shape[1])   # patchify folded in; row0 = 1 when pred still has its CLS row
+        # patchify folded in; row0 = 1 when pred still has its CLS row
+        return Fn.MaeReconLossFn.apply(pred, imgs, mask, ph, pw, pred.shape[1] - mask.shape[1], bool(self.norm_pix_loss))
 
     def forward(self, imgs, mask_ratio=0, mean_pool=False, return_all=False, masked_recon=False, noise=None):
         if masked_recon or return_all:

@@ -11,10 +11,23 @@ from .audiontt import AudioNTT2022, AudioNTT2022Encoder  # noqa: F401  (model.py
 
 
 def _chunked_mlp(x, ncrops, seq):
-    """Shared by head and predictor: the MLP (with its BatchNorm statistics) is applied per crop chunk."""
-    lin0, bn, _, lin1 = seq[0], seq[1], seq[2], seq[3]
+    """Shared by head and predictor: the MLP (with its BatchNorm statistics) is applied per crop chunk.  `seq` is the reference's
+    nn.Sequential: n x [Linear, BatchNorm1d, ReLU] + [Linear] (model.py:16-22).  The last hidden block and the output Linear run as one
+    fused schedule (Fn.MlpBnReluFn -- the whole projector for the default n = 1), hidden blocks before it as Fn.LinearBnReluFn, and
+    n = 0 is a plain Linear."""
+    n_hidden = (len(seq) - 1) // 3
     outs = []
     for _x in x.chunk(ncrops):
+        for i in range(n_hidden - 1):
+            lin, bn = seq[3 * i], seq[3 * i + 1]
+            _x = Fn.LinearBnReluFn.apply(_x, lin.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        if n_hidden == 0:
+            outs.append(Fn.LinearFn.apply(_x, seq[0].weight, None))
+            continue
+        k = 3 * (n_hidden - 1)
+        lin0, bn, lin1 = seq[k], seq[k + 1], seq[k + 3]
         outs.append(Fn.MlpBnReluFn.apply(_x, lin0.weight, bn.weight, bn.bias, lin1.weight, bn.running_mean, bn.running_var))
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -25,8 +38,6 @@ class BarlowTwinsHead(nn.Module):
     def __init__(self, cfg, in_dim):
         super().__init__()
         self.cfg = cfg
-        if self.cfg.projector_n_hidden_layers != 1:
-            raise NotImplementedError("the fused projector covers the reference default: one hidden layer (Linear-BN-ReLU-Linear)")
         sizes = [in_dim] + self.cfg.projector_n_hidden_layers * [self.cfg.projector_hidden_dim] + [self.cfg.projector_out_dim]
         layers = []
         for i in range(len(sizes) - 2):

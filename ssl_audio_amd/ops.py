@@ -475,22 +475,22 @@ def mae_unshuffle_bwd(dout, keep, ids_restore, dx, dmask_token):
                                      _p(dmask_token), _stream()), "sa_mae_unshuffle_bwd")
 
 
-def mae_recon_loss_fwd(pred, row0, img, mask, ph, pw, acc2, loss):
+def mae_recon_loss_fwd(pred, row0, img, mask, ph, pw, acc2, loss, norm_pix=False):
     """pred: contiguous [B, row0 + L, P] (row0 = 1: decoder output with its CLS row, read in place)."""
     B, _, F_, T_ = img.shape
     check(lib().sa_mae_recon_loss_fwd(_p(_req(pred, F32, "pred")), pred.shape[1] * pred.shape[2], row0, _p(_req(img, F32, "img")),
-                                      _p(_req(mask, F32, "mask")), B, F_, T_, ph, pw, _p(_req(acc2, F32, "acc2")), _p(_req(loss, F32, "loss")),
-                                      _stream()), "sa_mae_recon_loss_fwd")
+                                      _p(_req(mask, F32, "mask")), B, F_, T_, ph, pw, int(bool(norm_pix)), _p(_req(acc2, F32, "acc2")),
+                                      _p(_req(loss, F32, "loss")), _stream()), "sa_mae_recon_loss_fwd")
 
 
 def mae_recon_loss_finalize(acc2, loss):
     check(lib().sa_mae_recon_loss_finalize(_p(_req(acc2, F32, "acc2")), _p(_req(loss, F32, "loss")), _stream()), "sa_mae_recon_loss_finalize")
 
 
-def mae_recon_loss_bwd(pred, row0, img, mask, ph, pw, acc2, gscale, dpred):
+def mae_recon_loss_bwd(pred, row0, img, mask, ph, pw, acc2, gscale, dpred, norm_pix=False):
     B, _, F_, T_ = img.shape
     check(lib().sa_mae_recon_loss_bwd(_p(pred), pred.shape[1] * pred.shape[2], row0, _p(img), _p(mask), _p(acc2), _p(_req(gscale, F32, "gscale")),
-                                      B, F_, T_, ph, pw, _p(_req(dpred, F32, "dpred")), _stream()), "sa_mae_recon_loss_bwd")
+                                      B, F_, T_, ph, pw, int(bool(norm_pix)), _p(_req(dpred, F32, "dpred")), _stream()), "sa_mae_recon_loss_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ convolutional stems (NHWC)

@@ -69,3 +69,20 @@ def interpolate_pos_encoding(pos_embed, grid, freq_bins, frames, patch=(16, 16))
     rows = sum(P[iy[k]] * wy[k][:, None, None] for k in range(4))
     out = sum(rows[:, ix[k]] * wx[k][None, :, None] for k in range(4))
     return np.concatenate([pos_embed[:, :1], out.reshape(1, nf * nt, d)], axis=1)
+
+
+def interpolation_matrix(grid, nf, nt):
+    """The bicubic resampling of interpolate_pos_encoding as a matrix A [nf * nt, gh * gw] (out = A @ patch table), WITHOUT the
+    same-size shortcut: with `--use_learned_pos_embd` the reference resamples its table whenever the input is not square, even at the
+    table's own grid (models/mae.py:370-375; the +0.1 makes that resampling differ from the identity), and the table's gradient is
+    A^T applied to the summed token gradient."""
+    gh, gw = grid
+    sf, st = (nf + 0.1) / gh, (nt + 0.1) / gw
+    assert int(math.floor(gh * sf)) == nf and int(math.floor(gw * st)) == nt
+    iy, wy = _taps(gh, nf, sf)
+    ix, wx = _taps(gw, nt, st)
+    Ay, Ax = np.zeros((nf, gh)), np.zeros((nt, gw))
+    for k in range(4):
+        np.add.at(Ay, (np.arange(nf), iy[k]), wy[k])
+        np.add.at(Ax, (np.arange(nt), ix[k]), wx[k])
+    return np.kron(Ay, Ax)

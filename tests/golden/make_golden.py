@@ -795,7 +795,65 @@ def gen_hear():
     save("hear", **out)
 
 
+# ----------------------------------------------------------------------------- non-default options of the path (round 4)
+def gen_options():
+    """Options the reference exposes that are off by default: `--projector_n_hidden_layers` != 1 (model.py:16-22), the learned
+    positional embedding (`--use_learned_pos_embd`, models/mae.py:196-199) and `norm_pix_loss` (models/mae.py:443-446)."""
+    out = {}
+    # ---- projector depth 2 and 0
+    for tag, nh in (("h2", 2), ("h0", 0)):
+        cfg = cfg_ns(projector_hidden_dim=192, projector_out_dim=64, projector_n_hidden_layers=nh)
+        torch.manual_seed(10 + nh)
+        head = ref_model.BarlowTwinsHead(cfg, in_dim=128)
+        with torch.no_grad():
+            for m in head.projector:
+                if isinstance(m, nn.BatchNorm1d):
+                    m.weight.add_(0.2 * torch.randn(m.weight.shape))
+                    m.bias.add_(0.2 * torch.randn(m.bias.shape))
+        for k, v in head.state_dict().items():
+            out[f"{tag}_sd." + k] = t2n(v)
+        x = torch.randn(2 * 12, 128, requires_grad=True)
+        z = head(x, ncrops=2)
+        w = torch.randn_like(z)
+        (z * w).sum().backward()
+        out.update({f"{tag}_x": t2n(x), f"{tag}_z": t2n(z), f"{tag}_w": t2n(w), f"{tag}_dx": t2n(x.grad)})
+        for n, p in head.named_parameters():
+            out[f"{tag}_grad." + n] = t2n(p.grad)
+        for k, v in head.state_dict().items():
+            out[f"{tag}_sd_after." + k] = t2n(v)
+    # ---- learned positional embedding: micro ViT, T = 96 (the table's own grid: no interpolation), CLS latent, linear loss
+    torch.manual_seed(21)
+    vit = ref_mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                       norm_layer=partial(nn.LayerNorm, eps=1e-6), use_learned_pos_embd=True)
+    perturb_(vit, 22)
+    with torch.no_grad():
+        vit.pos_embed.add_(0.05 * torch.randn(vit.pos_embed.shape))
+    assert vit.pos_embed.requires_grad
+    for k, v in vit.state_dict().items():
+        out["lpe_sd." + k] = t2n(v)
+    x = torch.randn(3, 1, 64, 96)
+    lat = vit(x)
+    w = torch.randn_like(lat)
+    (lat * w).sum().backward()
+    out.update(lpe_x=t2n(x), lpe_latent=t2n(lat), lpe_w=t2n(w), lpe_dpos=t2n(vit.pos_embed.grad), lpe_dcls=t2n(vit.cls_token.grad),
+               lpe_dqkv0=t2n(vit.blocks[0].attn.qkv.weight.grad))
+    # ---- norm_pix_loss: decoder + reconstruction loss with per-patch normalised targets
+    torch.manual_seed(23)
+    mvit = ref_mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                        norm_layer=partial(nn.LayerNorm, eps=1e-6), use_decoder=True, decoder_embed_dim=64, decoder_depth=1,
+                                        decoder_num_heads=1, norm_pix_loss=True)
+    imgs = torch.randn(3, 1, 64, 96) * 1.7 + 0.4
+    pred = torch.randn(3, 24, 256, requires_grad=True)
+    mask = (torch.rand(3, 24) < 0.6).float()
+    mask[0, 0] = 1.0
+    loss = mvit.forward_loss(imgs, pred, mask)
+    loss.backward()
+    out.update(npl_imgs=t2n(imgs), npl_pred=t2n(pred), npl_mask=t2n(mask), npl_loss=t2n(loss), npl_dpred=t2n(pred.grad))
+    save("options", **out)
+
+
 if __name__ == "__main__":
+    gen_options() if "options" in sys.argv[1:] else None
     gen_hear() if "hear" in sys.argv[1:] else None
     gen_resnet() if "resnet" in sys.argv[1:] else None
     gen_convstem() if "convstem" in sys.argv[1:] else None

@@ -176,7 +176,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
         "sa_attention_fwd": lambda: h.sa_attention_fwd(one, 8, 2304, 768, 12, 300, 0, 0.125, one, 768, null, null),
         "sa_gather_rows": lambda: h.sa_gather_rows(one, 0, 0, one, 4, one, 0, 0, 2, 6, null),
         "sa_mae_unshuffle_fwd": lambda: h.sa_mae_unshuffle_fwd(one, 9, one, one, one, 2, 8, 64, one, null),
-        "sa_mae_recon_loss_fwd": lambda: h.sa_mae_recon_loss_fwd(one, 10, 1, one, one, 2, 60, 96, 16, 16, one, one, null),
+        "sa_mae_recon_loss_fwd": lambda: h.sa_mae_recon_loss_fwd(one, 10, 1, one, one, 2, 60, 96, 16, 16, 0, one, one, null),
         "sa_mean_tokens_fwd": lambda: h.sa_mean_tokens_fwd(one, 2, 1, 64, one, null),
     }
     for name, call in cases.items():

@@ -35,10 +35,10 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def micro_vit(dev, use_decoder=False, img_size=(64, 96)):
+def micro_vit(dev, use_decoder=False, img_size=(64, 96), **kw):
     m = mae.MaskedAutoencoderViT(img_size=img_size, patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
                                  norm_layer=partial(nn.LayerNorm, eps=1e-6), use_decoder=use_decoder, decoder_embed_dim=64,
-                                 decoder_depth=1, decoder_num_heads=1)
+                                 decoder_depth=1, decoder_num_heads=1, **kw)
     return m.to(dev)
 
 
@@ -241,6 +241,79 @@ def test_mae_decoder_golden(dev, golden, tag, img):
     for k in [k for k in g if k.startswith(f"{tag}_grad.")]:
         n = k[len(f"{tag}_grad."):]
         assert rel(named[n].grad, g[k]) < 6e-2, n
+
+
+def test_options_projector_depth_learned_pos_norm_pix_golden(dev, golden):
+    """Round 4: the options the earlier rounds refused -- `--projector_n_hidden_layers` 2 / 0 (model.py:16-22), `--use_learned_pos_embd`
+    (models/mae.py:198-199, :370-392: gradient of the trained table through the reference's bicubic resampling of non-square inputs, with
+    and without random masking) and `norm_pix_loss` (models/mae.py:443-446) -- against the reference's outputs (tests/golden/options.npz);
+    tolerances of the default-option tests (bf16 GEMM operands)."""
+    g = golden("options")
+    for tag, nh in (("h2", 2), ("h0", 0)):
+        cfg = hp.make_args(model_type="vit_tiny", projector_hidden_dim=192, projector_out_dim=64, projector_n_hidden_layers=nh)
+        head = model.BarlowTwinsHead(cfg, 128).to(dev)
+        load_prefixed(head, g, f"{tag}_sd.", dev)
+        x = T(g[f"{tag}_x"], dev).requires_grad_(True)
+        z = head(x, ncrops=2)
+        assert rel(z, g[f"{tag}_z"]) < 1e-2, tag
+        (z * T(g[f"{tag}_w"], dev)).sum().backward()
+        errs = {"dx": rel(x.grad, g[f"{tag}_dx"])}
+        for n, p in head.named_parameters():
+            errs[n] = rel(p.grad, g[f"{tag}_grad." + n])
+        print(tag, "head grad rel errors vs the fp32 reference:", {k: round(v, 4) for k, v in errs.items()})
+        # Twelve rows per crop chunk through TWO BatchNorm + ReLU layers: bf16 GEMM operands flip ReLU decisions and move 12-row batch
+        # statistics, so the distance to the fp32 reference is bf16 sensitivity (8-9 % measured behind both ReLUs); what discriminates is
+        # the oracle rounding where the HIP path stores bf16 (oracle/rounding.py): the two must agree to 3e-2
+        assert max(errs.values()) < (6e-2 if nh == 0 else 2e-1), errs
+        from oracle import heads as oheads, rounding as R
+        sdo = {k[len(f"{tag}_sd."):]: T(v) for k, v in g.items() if k.startswith(f"{tag}_sd.")}
+        leaves = {k: v.requires_grad_(True) for k, v in sdo.items() if "running" not in k and "num_batches" not in k}
+        xo = T(g[f"{tag}_x"]).requires_grad_(True)
+        with R.mirror_hip_bf16():
+            zo, _ = oheads.head_forward(xo, sdo, ncrops=2)
+            (zo * T(g[f"{tag}_w"])).sum().backward()
+        merr = {"dx": rel(x.grad, xo.grad)}
+        for n, p in head.named_parameters():
+            merr[n] = rel(p.grad, leaves[n].grad)
+        print(tag, "head grad rel errors vs the bf16-mirror oracle:", {k: round(v, 4) for k, v in merr.items()})
+        assert max(merr.values()) < 3e-2, merr
+        sd = head.state_dict()
+        for k in [k for k in g if k.startswith(f"{tag}_sd_after.") and "running" in k]:
+            assert rel(sd[k[len(f"{tag}_sd_after."):]], g[k]) < 1e-2, k
+        for k in [k for k in g if k.startswith(f"{tag}_sd_after.") and "num_batches" in k]:
+            assert int(sd[k[len(f"{tag}_sd_after."):]]) == int(g[k]) == 2
+    # ---- learned positional embedding
+    m = micro_vit(dev, use_learned_pos_embd=True)
+    load_prefixed(m, g, "lpe_sd.", dev)
+    assert m.pos_embed.requires_grad
+    x = T(g["lpe_x"], dev)
+    lat = m(x)
+    assert rel(lat, g["lpe_latent"]) < 2e-2
+    m.zero_grad()
+    (lat * T(g["lpe_w"], dev)).sum().backward()
+    assert rel(m.pos_embed.grad, g["lpe_dpos"]) < 5e-2 and rel(m.cls_token.grad, g["lpe_dcls"]) < 5e-2
+    assert rel(m.blocks[0].attn.qkv.weight.grad, g["lpe_dqkv0"]) < 5e-2
+    # random masking: only kept positions (and the CLS slot) receive a table gradient; equals the oracle on the same mask
+    from oracle import vit as ovit
+    mask = torch.zeros(3, 24)
+    mask[:, 1::2] = 1.0
+    m.zero_grad()
+    w = torch.linspace(-1, 1, 3 * 128, device=dev).reshape(3, 128)
+    (m(x, mask_ratio=mask.to(dev)) * w).sum().backward()
+    p = {k[len("lpe_sd."):]: T(v) for k, v in g.items() if k.startswith("lpe_sd.")}
+    p["pos_embed"].requires_grad_(True)
+    (ovit.forward(T(g["lpe_x"]), p, 2, (4, 6), mask=mask, learned_pos=True) * w.cpu()).sum().backward()
+    assert rel(m.pos_embed.grad, p["pos_embed"].grad) < 5e-2
+    m64 = micro_vit(dev, use_learned_pos_embd=True, img_size=(64, 64))          # square input at the table's grid: the table itself
+    pos64, A64 = m64._learned_pos(64, 64)
+    assert A64 is None and pos64 is m64.pos_embed
+    # ---- norm_pix_loss
+    mm = micro_vit(dev, use_decoder=True, norm_pix_loss=True)
+    pred = T(g["npl_pred"], dev).requires_grad_(True)
+    loss = mm.forward_loss(T(g["npl_imgs"], dev), pred, T(g["npl_mask"], dev))
+    assert abs(float(loss) - float(g["npl_loss"])) <= 1e-5 * float(g["npl_loss"])
+    loss.backward()
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), g["npl_dpred"], rtol=1e-4, atol=1e-8)
 
 
 def test_param_counts_and_keys():

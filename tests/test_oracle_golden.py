@@ -239,6 +239,44 @@ def test_head_and_predictor(golden):
     assert int(st["projector.1.num_batches_tracked"]) == int(g["head_sd_after.projector.1.num_batches_tracked"])
 
 
+# ----------------------------------------------------------------------------- non-default options (round 4)
+def test_options_projector_depth_learned_pos_norm_pix(golden):
+    """`--projector_n_hidden_layers` 2 and 0 (model.py:16-22), `--use_learned_pos_embd` (models/mae.py:198-199, :370-392: a trained table,
+    resampled for non-square inputs, gradient through the resampling) and `norm_pix_loss` (models/mae.py:443-446) against the reference's
+    own outputs and gradients (tests/golden/options.npz)."""
+    g = golden("options")
+    for tag in ("h2", "h0"):
+        sd = {k[len(tag + "_sd."):]: T(v) for k, v in g.items() if k.startswith(tag + "_sd.")}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+        x = T(g[tag + "_x"]).requires_grad_(True)
+        z, stats = oh.head_forward(x, sd, ncrops=2)
+        np.testing.assert_allclose(z.detach().numpy(), g[tag + "_z"], atol=2e-5)
+        (z * T(g[tag + "_w"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), g[tag + "_dx"], rtol=1e-3, atol=2e-6)
+        for k, v in leaves.items():
+            np.testing.assert_allclose(v.grad.numpy(), g[f"{tag}_grad.{k}"], rtol=2e-3, atol=5e-6, err_msg=k)
+        assert len(stats) == {"h2": 4, "h0": 0}[tag]                       # two BatchNorms x two crop chunks / none
+    p = {k[len("lpe_sd."):]: T(v) for k, v in g.items() if k.startswith("lpe_sd.")}
+    for k in ("pos_embed", "cls_token", "blocks.0.attn.qkv.weight"):
+        p[k].requires_grad_(True)
+    lat = ovit.forward(T(g["lpe_x"]), p, 2, (4, 6), learned_pos=True)
+    np.testing.assert_allclose(lat.detach().numpy(), g["lpe_latent"], atol=3e-5)
+    (lat * T(g["lpe_w"])).sum().backward()
+    np.testing.assert_allclose(p["pos_embed"].grad.numpy(), g["lpe_dpos"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(p["cls_token"].grad.numpy(), g["lpe_dcls"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(p["blocks.0.attn.qkv.weight"].grad.numpy(), g["lpe_dqkv0"], rtol=2e-3, atol=5e-6)
+    # the resampling of the trained table as a matrix (what the HIP path multiplies by) == torch's bicubic interpolate
+    from ssl_audio_amd.pos_embed import interpolation_matrix
+    A = torch.from_numpy(interpolation_matrix((4, 6), 4, 6)).float()
+    ref = ovit.learned_pos_table(T(g["lpe_sd.pos_embed"]), (4, 6), 64, 96)[0, 1:]
+    np.testing.assert_allclose((A @ T(g["lpe_sd.pos_embed"])[0, 1:]).numpy(), ref.numpy(), atol=2e-6)
+    pred = T(g["npl_pred"]).requires_grad_(True)
+    loss = ovit.recon_loss(T(g["npl_imgs"]), pred, T(g["npl_mask"]), (4, 6), norm_pix=True)
+    np.testing.assert_allclose(float(loss), float(g["npl_loss"]), rtol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(pred.grad.numpy(), g["npl_dpred"], rtol=1e-4, atol=1e-8)
+
+
 # ----------------------------------------------------------------------------- full step
 @pytest.mark.parametrize("tag,stop_grad,use_pred", [("byol", True, True), ("plain", False, False)])
 def test_full_step(golden, tag, stop_grad, use_pred):
