@@ -7,9 +7,10 @@
 //             sa_bt_bwd_apply     dz of both views
 //
 // against the fifteen of the piecewise schedule (bn_colstats x2, bn_finalize x2, bn_apply x2, matmul_f32 x3, bn_bwd_stats x2,
-// bn_bwd_apply x2, bt_loss_grad x2).  Same arithmetic: the normalised values, the cross-correlation, the loss and the two gradient
-// products are bit-identical to the piecewise kernels' (fp32 throughout, products on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32, same
-// k-order); the BatchNorm backward column sums add their rows in another (fixed) order, so dz agrees to fp32 rounding.  What it buys
+// bn_bwd_apply x2, bt_loss_grad x2).  Same arithmetic, fp32 throughout, products on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32: the
+// normalised values and the two gradient products are bit-identical to the piecewise kernels'; the cross-correlation adds its rows in
+// four contiguous quarters and the BatchNorm backward sums in another (fixed) order, so c, the loss and dz agree to fp32 rounding
+// (and are bit-reproducible run to run).  What it buys
 // is launches on the critical path between the forward and the backward of a step: 16.8 MFLOP and 256 KiB at B = 128, D = 256 are latency.
 #include "common.h"
 #include "../../include/ssl_audio_hip.h"
@@ -73,17 +74,20 @@ __device__ __forceinline__ void combine(const float* __restrict__ st, int64_t ra
   var_unbiased = m2 / fmaxf(n - 1.f, 1.f);
 }
 
-// ---- one wave per 32 x 32 tile (ti, tj) of c: statistics of its 32 view-1 columns and 32 view-2 columns combined over the ranks,
-// the two views normalised in registers (zn = (z - mean) * rstd, the expression of bn_apply_kernel) and fed to the MFMA as
-// A(i, b) = z1n[b][i], B(b, j) = z2n[b][j] -- the k-order of matmul_f32_kernel.  Tiles of the first tile row / column also write
-// the normalised views and mean / rstd (saved for the backward); the DIAGONAL tiles update the running buffers, view 1 then view 2,
-// as bn(z1), bn(z2) do (utils/loss.py:17).  allst: [W][2][2][D] (the all-gathered sa_bt_stats2 output).
-__global__ __launch_bounds__(64) void bt_corr_kernel(const float* __restrict__ z1, const float* __restrict__ z2, int64_t ld, int B, int D,
-                                                     const float* __restrict__ allst, int W, float eps, float momentum, float inv_n,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
-                                                     float* __restrict__ running_var, float* __restrict__ z1n, float* __restrict__ z2n,
-                                                     float* __restrict__ c) {
-  const int lane = threadIdx.x;
+// ---- one workgroup (four waves) per 32 x 32 tile (ti, tj) of c: statistics of its 32 view-1 columns and 32 view-2 columns combined over
+// the ranks, the two views normalised in registers (zn = (z - mean) * rstd, the expression of bn_apply_kernel) and fed to the MFMA as
+// A(i, b) = z1n[b][i], B(b, j) = z2n[b][j].  The four waves split the rows b (the reduction) into contiguous quarters and their partial
+// tiles meet in LDS in wave order: at 16.8 MFLOP the product is a chain of load latencies, so it is cut four ways and every wave has the
+// next 16 rows' loads in flight while it multiplies the current 16.  Tiles of the first tile row / column also write the normalised
+// views and mean / rstd (saved for the backward); the DIAGONAL tiles update the running buffers, view 1 then view 2, as bn(z1), bn(z2)
+// do (utils/loss.py:17).  allst: [W][2][2][D] (the all-gathered sa_bt_stats2 output).
+__global__ __launch_bounds__(256) void bt_corr_kernel(const float* __restrict__ z1, const float* __restrict__ z2, int64_t ld, int B, int D,
+                                                      const float* __restrict__ allst, int W, float eps, float momentum, float inv_n,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, float* __restrict__ z1n, float* __restrict__ z2n,
+                                                      float* __restrict__ c) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ti = blockIdx.y, tj = blockIdx.x;
   const int i = lane & 31, kk = lane >> 5;
   const int ci = ti * 32 + i, cj = tj * 32 + i;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(64) void bt_corr_kernel(const float* __restrict__ z
   const int64_t rs = (int64_t)4 * D;                       // one rank's [2][2][D] block
   if (iv) combine(allst, rs, W, B, D, ci, eps, mu1, r1, vu1);
   if (jv) combine(allst + 2 * D, rs, W, B, D, cj, eps, mu2, r2, vu2);
-  if (kk == 0) {
+  if (wave == 0 && kk == 0) {
     if (tj == 0 && iv) { mean_out[ci] = mu1; rstd_out[ci] = r1; }
     if (ti == 0 && jv) { mean_out[D + cj] = mu2; rstd_out[D + cj] = r2; }
     if (ti == tj && iv) {                                   // (ci == cj here)
@@ -108,50 +112,68 @@ __global__ __launch_bounds__(64) void bt_corr_kernel(const float* __restrict__ z
       }
     }
   }
-  const float* ap = z1 + ci;
-  const float* bp = z2 + cj;
-  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 8 <= B; k += 8) {
-    float a[4], b[4];
+  const int per = ((B + 3) / 4 + 1) & ~1;                  // rows per wave (even: a lane pair covers rows k, k + 1)
+  const int k_lo = wave * per, k_hi = min(B, k_lo + per);
+  const float* ap = z1 + (iv ? ci : 0);
+  const float* bp = z2 + (jv ? cj : 0);
+  // rows past k_hi read row 0 (always valid) and are zeroed; a chunk = 16 rows = 8 MFMAs
+  auto load_chunk = [&](int k, float (&a)[8], float (&b)[8]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int kq = k + 2 * u + kk;
-      a[u] = iv ? (ap[(int64_t)kq * ld] - mu1) * r1 : 0.f;
-      b[u] = jv ? (bp[(int64_t)kq * ld] - mu2) * r2 : 0.f;
-      if (tj == 0 && iv) z1n[(int64_t)kq * D + ci] = a[u];
-      if (ti == 0 && jv) z2n[(int64_t)kq * D + cj] = b[u];
+      const int64_t row = kq < k_hi ? kq : 0;
+      a[u] = ap[row * ld];
+      b[u] = bp[row * ld];
     }
+  };
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float a0[8], b0[8], a1[8], b1[8];
+  if (k_lo < k_hi) load_chunk(k_lo, a0, b0);
+  for (int k = k_lo; k < k_hi; k += 16) {
+    const bool more = k + 16 < k_hi;
+    if (more) load_chunk(k + 16, a1, b1);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-  }
-  for (; k < B; k += 2) {
-    const int kq = k + kk;
-    const float a = (iv && kq < B) ? (ap[(int64_t)kq * ld] - mu1) * r1 : 0.f;
-    const float b = (jv && kq < B) ? (bp[(int64_t)kq * ld] - mu2) * r2 : 0.f;
-    if (kq < B) {
-      if (tj == 0 && iv) z1n[(int64_t)kq * D + ci] = a;
-      if (ti == 0 && jv) z2n[(int64_t)kq * D + cj] = b;
+    for (int u = 0; u < 8; ++u) {
+      const int kq = k + 2 * u + kk;
+      const bool live = kq < k_hi;
+      const float av = (iv && live) ? (a0[u] - mu1) * r1 : 0.f;
+      const float bv = (jv && live) ? (b0[u] - mu2) * r2 : 0.f;
+      if (live) {
+        if (tj == 0 && iv) z1n[(int64_t)kq * D + ci] = av;
+        if (ti == 0 && jv) z2n[(int64_t)kq * D + cj] = bv;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-  }
-  // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int n = tj * 32 + (lane & 31);
+    if (more) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m < D && n < D) c[(int64_t)m * D + n] = inv_n * acc[r];
+      for (int u = 0; u < 8; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+    // C/D layout 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int n = tj * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float t = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+      if (m < D && n < D) c[(int64_t)m * D + n] = inv_n * t;
+    }
   }
 }
 
-// ---- backward products with their BatchNorm column sums.  blockIdx.y = view, blockIdx.x = 32-column tile; four waves, wave w takes the
-// 32-row tiles w, w + 4, ...:  view 0: dz1n[b][i] = inv_n * sum_j z2n[b][j] G[i][j]; view 1: dz2n[b][j] = inv_n * sum_i z1n[b][i] G[i][j]
-// (the operand order and k-order of the two matmul_f32 launches they replace), then s1 = sum_b dzn, s2 = sum_b dzn * zn per column:
-// a lane holds 16 rows of one column, the two half-waves and the four waves meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void bt_bwd_products_kernel(const float* __restrict__ z1n, const float* __restrict__ z2n, int B, int D,
-                                                              const float* __restrict__ G, float inv_n, float* __restrict__ dzn,
-                                                              float* __restrict__ s) {
-  __shared__ float red[2][8][32];
+// ---- backward products with their BatchNorm column sums.  blockIdx.y = view, blockIdx.x = 32-column tile; EIGHT waves, wave w takes the
+// 32-row tiles w, w + 8, ...:  view 0: dz1n[b][i] = inv_n * sum_j z2n[b][j] G[i][j]; view 1: dz2n[b][j] = inv_n * sum_i z1n[b][i] G[i][j]
+// (the operand order and k-order of the two matmul_f32 launches they replace; the next 16 k's loads travel while the current 16 are
+// multiplied), then s1 = sum_b dzn, s2 = sum_b dzn * zn per column: a lane holds 16 rows of one column, the two half-waves and the
+// eight waves meet in LDS in a fixed order.
+constexpr int BP_WAVES = 8;
+__global__ __launch_bounds__(64 * BP_WAVES) void bt_bwd_products_kernel(const float* __restrict__ z1n, const float* __restrict__ z2n, int B, int D,
+                                                                        const float* __restrict__ G, float inv_n, float* __restrict__ dzn,
+                                                                        float* __restrict__ s) {
+  __shared__ float red[2][2 * BP_WAVES][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int view = blockIdx.y;
   const float* A = view == 0 ? z2n : z1n;                  // A(m, k) = A[m * D + k]
@@ -162,29 +184,35 @@ __global__ __launch_bounds__(256) void bt_bwd_products_kernel(const float* __res
   const bool nv = (n0 + i) < D;
   // B(k, n): view 0: G[n][k] (stride D over n, 1 over k); view 1: G[k][n]
   const int64_t sbk = view == 0 ? 1 : D, sbn = view == 0 ? D : 1;
-  const float* bp = G + (int64_t)(n0 + i) * sbn;
+  const float* bp = G + (int64_t)(nv ? n0 + i : 0) * sbn;
   float s1 = 0.f, s2 = 0.f;
-  for (int m0 = wave * 32; m0 < B; m0 += 4 * 32) {
+  for (int m0 = wave * 32; m0 < B; m0 += BP_WAVES * 32) {
     const bool mv = (m0 + i) < B;
-    const float* ap = A + (int64_t)(m0 + i) * D;
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= D; k += 8) {
-      float a[4], b[4];
+    const float* ap = A + (int64_t)(mv ? m0 + i : 0) * D;
+    auto load_chunk = [&](int k, float (&a)[8], float (&b)[8]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int kq = k + 2 * u + kk;
-        a[u] = mv ? ap[kq] : 0.f;
-        b[u] = nv ? bp[(int64_t)kq * sbk] : 0.f;
+        const int kc = kq < D ? kq : 0;
+        a[u] = ap[kc];
+        b[u] = bp[(int64_t)kc * sbk];
       }
+    };
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float a0[8], b0[8], a1[8], b1[8];
+    load_chunk(0, a0, b0);
+    for (int k = 0; k < D; k += 16) {
+      const bool more = k + 16 < D;
+      if (more) load_chunk(k + 16, a1, b1);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-    }
-    for (; k < D; k += 2) {
-      const int kq = k + kk;
-      const float a = (mv && kq < D) ? ap[kq] : 0.f;
-      const float b = (nv && kq < D) ? bp[(int64_t)kq * sbk] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        const bool live = k + 2 * u + kk < D;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((mv && live) ? a0[u] : 0.f, (nv && live) ? b0[u] : 0.f, acc, 0, 0, 0);
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; }
+      }
     }
     const int n = n0 + (lane & 31);
 #pragma unroll
@@ -204,7 +232,7 @@ __global__ __launch_bounds__(256) void bt_bwd_products_kernel(const float* __res
   if (threadIdx.x < 32 && n0 + (int)threadIdx.x < D) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+    for (int q = 0; q < 2 * BP_WAVES; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
     float* sv = s + (int64_t)view * 2 * D;
     sv[n0 + threadIdx.x] = a;
     sv[D + n0 + threadIdx.x] = b;
@@ -244,7 +272,7 @@ extern "C" int sa_bt_corr(const float* z1, const float* z2, int64_t ld, int32_t 
                           float* c, void* stream) {
   SA_CHECK_ARG(z1 && z2 && all_stats && mean && rstd && z1n && z2n && c && B > 0 && D > 0 && W > 0 && ld >= D, "sa_bt_corr: bad args");
   const int t = (D + 31) / 32;
-  hipLaunchKernelGGL(bt_corr_kernel, dim3(t, t), dim3(64), 0, (hipStream_t)stream, z1, z2, ld, B, D, all_stats, W, eps, momentum, inv_n, mean, rstd,
+  hipLaunchKernelGGL(bt_corr_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, z1, z2, ld, B, D, all_stats, W, eps, momentum, inv_n, mean, rstd,
                      running_mean, running_var, z1n, z2n, c);
   SA_LAUNCH_CHECK("sa_bt_corr");
   return 0;
@@ -253,7 +281,7 @@ extern "C" int sa_bt_corr(const float* z1, const float* z2, int64_t ld, int32_t 
 extern "C" int sa_bt_bwd_products(const float* z1n, const float* z2n, int32_t B, int32_t D, const float* G, float inv_n, float* dzn, float* sums,
                                   void* stream) {
   SA_CHECK_ARG(z1n && z2n && G && dzn && sums && B > 0 && D > 0, "sa_bt_bwd_products: bad args");
-  hipLaunchKernelGGL(bt_bwd_products_kernel, dim3((D + 31) / 32, 2), dim3(256), 0, (hipStream_t)stream, z1n, z2n, B, D, G, inv_n, dzn, sums);
+  hipLaunchKernelGGL(bt_bwd_products_kernel, dim3((D + 31) / 32, 2), dim3(64 * BP_WAVES), 0, (hipStream_t)stream, z1n, z2n, B, D, G, inv_n, dzn, sums);
   SA_LAUNCH_CHECK("sa_bt_bwd_products");
   return 0;
 }

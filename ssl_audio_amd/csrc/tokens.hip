@@ -124,6 +124,9 @@ __global__ void mae_unshuffle_kernel(const float* __restrict__ x, int keep, cons
   }
 }
 
+constexpr int UNSH_MAXD = 2048, UNSH_GROUPS = 128;
+__device__ float unshuffle_partials[UNSH_GROUPS * UNSH_MAXD];     // per row group: the mask-token gradient partial (one launch at a time per stream)
+
 // adjoint: dx rows are a permutation of the kept rows of dout (written, not accumulated); dmask_token += sum over masked rows.
 // One block column per 64 float4 columns, blockIdx.y strides over (b, row); the mask-token partial stays in registers.
 __global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __restrict__ dout, int keep, const int* __restrict__ ids_restore, int B, int L,
@@ -151,9 +154,17 @@ __global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __r
   if (wave == 0 && c < nv && dmask) {
     float4 t = red[0][lane];
     for (int w = 1; w < 4; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
-    atomicAdd(dmask + 4 * c + 0, t.x); atomicAdd(dmask + 4 * c + 1, t.y);
-    atomicAdd(dmask + 4 * c + 2, t.z); atomicAdd(dmask + 4 * c + 3, t.w);
+    // the row groups' partials are added in group order by mae_unshuffle_sum_kernel (no float atomics: bit-reproducible)
+    reinterpret_cast<float4*>(unshuffle_partials + (int64_t)blockIdx.y * UNSH_MAXD)[c] = t;
   }
+}
+
+__global__ void mae_unshuffle_sum_kernel(int ngroups, int d, float* __restrict__ dmask) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float t = 0.f;
+  for (int y = 0; y < ngroups; ++y) t += unshuffle_partials[(int64_t)y * UNSH_MAXD + c];
+  dmask[c] += t;
 }
 
 // ---- MAE reconstruction loss (models/mae.py:437-453, patchify :282-293; one input channel):
@@ -361,9 +372,11 @@ extern "C" int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32
   SA_CHECK_ARG(dout && ids_restore && dx && B > 0 && L > 0 && keep >= 0 && keep <= L && d > 0 && d % 4 == 0, "sa_mae_unshuffle_bwd: bad args");
   const int64_t rows = (int64_t)B * (L + 1);
   int gy = (int)((rows + 3) / 4);
-  if (gy > 128) gy = 128;
+  if (gy > UNSH_GROUPS) gy = UNSH_GROUPS;
+  SA_CHECK_ARG(d <= UNSH_MAXD, "sa_mae_unshuffle_bwd: d = %d exceeds %d", d, UNSH_MAXD);
   hipLaunchKernelGGL(mae_unshuffle_bwd_kernel, dim3((d / 4 + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, dout, keep, ids_restore, B, L, d, dx,
                      dmask_token);
+  if (dmask_token) hipLaunchKernelGGL(mae_unshuffle_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, d, dmask_token);
   SA_LAUNCH_CHECK("sa_mae_unshuffle_bwd");
   return 0;
 }
