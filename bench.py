@@ -162,6 +162,11 @@ def main():
     ap.add_argument("--batch_per_gpu", type=int, default=None)
     ap.add_argument("--global_batch", type=int, default=None, help="STRONG scaling: this many clips in all, split over the ranks "
                     "(BASELINE config 3's 1024); default is weak scaling at the workload's clips per GPU")
+    ap.add_argument("--dispatch", default="auto", choices=["auto", "direct", "torch_ops"], help="torch_ops: every kernel call of the step goes "
+                    "through torch.ops.ssl_audio.* (torch.library custom operators) instead of the direct ctypes call -- same kernels, same "
+                    "bits, ~3 us more host time per launch.  Measured (DESIGN.md section 6): free where the step is GPU-bound (ViT-B 41.10 vs "
+                    "41.10 ms), +12 %% where ~480 launches share 16 ms (ViT-T 16.1 -> 18.1 ms).  auto = torch_ops for the ViT-B / ViT-L "
+                    "workloads, direct for ViT-T")
     ap.add_argument("--dry_launch", action="store_true", help="print the child launcher command of the self-launch path and exit")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the device part of the step as ONE HIP graph (BarlowTwinsTrainer.enable_graph); "
@@ -191,6 +196,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.lib()                                                      # fail loudly if the HIP library is missing
+    if args.dispatch == "torch_ops" or (args.dispatch == "auto" and "tiny" not in WORKLOADS[args.workload][0]):
+        ops.route_through_dispatcher(True)
     dist_backend = torch.distributed.get_backend() if sdist.is_dist_avail_and_initialized() else None
     try:
         rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())      # RCCL's version (backend "nccl" IS RCCL on ROCm)
@@ -341,7 +348,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "encoder": model_type, "clip_seconds": seconds, "n_mels": 64,
                        "clips_per_gpu": B, "global_batch": B * world, "step": "logmel+augment+fwd+bwd+allreduce+adamw" +
-                       ("+ema" if mode == "byol" else ""), "hip_graph": trainer._graph is not None,
+                       ("+ema" if mode == "byol" else ""), "hip_graph": trainer._graph is not None, "dispatch": ops.DISPATCH,
                        "profiled_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
                        "loss": round(loss_val, 4),
                        "dist_world": sdist.get_world_size(), "dist_backend": dist_backend, "rccl_version": rccl_version,

@@ -632,3 +632,54 @@ def avgpool_fwd(x, B, L, C, out):
 
 def avgpool_bwd(dout, B, L, C, dx):
     check(lib().sa_avgpool_bwd(_p(_req(dout, F32, "dout")), B, L, C, _p(_req(dx, F32, "dx")), _stream()), "sa_avgpool_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ routing through torch.ops
+DISPATCH = "direct"          # "direct": ops.<name> IS the ctypes call; "torch_ops": it goes torch.ops.ssl_audio.<name> -> dispatcher -> ctypes call
+
+
+def route_through_dispatcher(on=True):
+    """Make every `ops.<name>(...)` of the engine / trainer go through `torch.ops.ssl_audio.<name>` (custom_ops.py: torch.library operators,
+    BASELINE's "driven from Python via PyTorch-ROCm custom ops") instead of calling the ctypes wrapper directly.  Same kernels, same
+    bits (tests/test_configs_gpu.py::test_step_through_the_dispatcher_equals_direct); what it costs is host time per launch (the
+    dispatcher + the Python-registered implementation: measured in DESIGN.md §6), so "direct" stays the default and
+    `SA_DISPATCH=torch_ops` (or bench.py --dispatch torch_ops) selects this route.  Idempotent; `on=False` restores the direct calls."""
+    global DISPATCH
+    import sys
+    from . import custom_ops                     # registers the operators against the ORIGINAL functions (captured at import)
+    mod = sys.modules[__name__]
+    direct = mod.__dict__.setdefault("_DIRECT_FNS", {})
+    if not on:
+        for name, fn in direct.items():
+            setattr(mod, name, fn)
+        DISPATCH = "direct"
+        return
+    ns = getattr(torch.ops, custom_ops.NAMESPACE)
+    for name in custom_ops.SCHEMAS:
+        if name in custom_ops._ADAPTERS:         # (the dispatcher signature differs from the ops function's: keep the direct call)
+            continue
+        direct.setdefault(name, getattr(mod, name))
+        op = getattr(ns, name)
+        if name in ("transpose_bf16", "cast_bf16"):              # the two that allocate their output when none is given
+
+            def alloc_wrapper(src, dst=None, _op=op, _name=name):
+                if dst is None:
+                    src = src if _name == "transpose_bf16" else src.contiguous()
+                    shape = (src.shape[1], src.shape[0]) if _name == "transpose_bf16" else tuple(src.shape)
+                    dst = torch.empty(shape, dtype=BF16, device=src.device)
+                _op(src, dst)
+                return dst
+            setattr(mod, name, alloc_wrapper)
+        elif name in ("colsum_bf16", "matmul_f32"):              # ... and the two that hand their output argument back
+
+            def out_wrapper(*args, _op=op, _pos=(1 if name == "colsum_bf16" else 2), **kwargs):
+                _op(*args, **kwargs)
+                return args[_pos] if len(args) > _pos else kwargs["out"]
+            setattr(mod, name, out_wrapper)
+        else:
+            setattr(mod, name, op)
+    DISPATCH = "torch_ops"
+
+
+if os.environ.get("SA_DISPATCH") == "torch_ops":
+    route_through_dispatcher(True)

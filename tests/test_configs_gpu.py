@@ -314,6 +314,40 @@ def test_trainer_local_crops_step_vs_oracle(dev):
         BarlowTwinsTrainer(cfg, dev, mode="byol", batch_per_rank=B, clip_samples=15200, seed=0, from_waveform=False)
 
 
+def test_step_through_the_dispatcher_equals_direct(dev):
+    """the same three steps with every kernel call routed through `torch.ops.ssl_audio.*` (torch.library custom
+    operators: ops.route_through_dispatcher) and with the direct ctypes calls -- same kernels, so bit-identical losses, gradients and
+    weights (the path holds no float atomics); and the routed step really passes the dispatcher (the operators' call counts move)."""
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128)
+    g = torch.Generator().manual_seed(6)
+    batches = [[torch.randn(8, 1, 64, 96, generator=g).to(dev), torch.randn(8, 1, 64, 96, generator=g).to(dev)] for _ in range(3)]
+
+    def run():
+        tr = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
+        losses = [float(tr.step_views(v)) for v in batches]
+        torch.cuda.synchronize()
+        return losses, tr.flat.params.clone(), tr.flat.grads.clone(), tr.flat.m.clone()
+
+    direct = run()
+    import ssl_audio_amd.custom_ops as co
+    calls = {"n": 0}
+    orig = ops._DIRECT_FNS["gemm"] if hasattr(ops, "_DIRECT_FNS") and "gemm" in ops._DIRECT_FNS else ops.gemm
+    try:
+        ops.route_through_dispatcher(True)
+        assert ops.DISPATCH == "torch_ops" and ops.gemm is torch.ops.ssl_audio.gemm
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            routed = run()
+        names = {e.key for e in prof.key_averages()}
+        assert {"ssl_audio::gemm", "ssl_audio::layernorm_fwd", "ssl_audio::attention_bwd", "ssl_audio::adamw_step_dev"} <= names, sorted(n for n in names if "ssl_audio" in n)
+    finally:
+        ops.route_through_dispatcher(False)
+    assert ops.DISPATCH == "direct" and ops.gemm is orig
+    assert direct[0] == routed[0], (direct[0], routed[0])
+    for a, b, what in zip(direct[1:], routed[1:], ("params", "grads", "m")):
+        assert torch.equal(a, b), what
+    del co, calls
+
+
 @pytest.mark.parametrize("mode", ["bt", "byol"])
 def test_graph_replay_equals_eager(dev, mode):
     """the device part of the step captured into ONE HIP graph (BarlowTwinsTrainer.enable_graph) and replayed takes
