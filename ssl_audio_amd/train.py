@@ -407,7 +407,7 @@ class BarlowTwinsTrainer:
         loader_len = iterations per epoch) and, in mode 'mae', the mask ratio (mask_ratio_for, main.py:71-81)."""
         if iteration is not None:
             self.apply_schedules(iteration, loader_len)
-            if mask_ratio is None and self.mode == "mae":
+            if mask_ratio is None and (self.mode == "mae" or getattr(self.cfg, "mask", False)):
                 mask_ratio = self.mask_ratio_for(iteration)
         return self.step_views(self.make_views(batch), mask_ratio=mask_ratio)
 
@@ -428,6 +428,8 @@ class BarlowTwinsTrainer:
         if self.mask_ratio_schedule is not None:
             return float(self.mask_ratio_schedule[iteration])
         if getattr(self.cfg, "random_mask_ratio", False):
+            if self.mode == "byol":                              # main_bt_byol.py:70-72: fixed U(0.02, 0.2)
+                return utils.generate_random(l=0.02, h=0.2, p=0.5)
             return utils.generate_random(l=0.05, h=self.cfg.mask_beta, p=0.5)
         return self.cfg.mask_ratio
 
@@ -442,7 +444,7 @@ class BarlowTwinsTrainer:
         self.flat.stage_hyper(g[0]["lr"], lr_nodecay=g[1]["lr"])
         if self.mode == "byol":
             self.flat_pred.stage_hyper(g[2]["lr"], lr_nodecay=g[3]["lr"])
-        if self._graph is not None and self.use_graph and mask_ratio is None:
+        if self._graph is not None and self.use_graph and mask_ratio is None and not getattr(self.cfg, "mask", False):
             for dst, src in zip(self._graph_views, views):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
@@ -459,11 +461,14 @@ class BarlowTwinsTrainer:
         """Everything of a step that runs on the device, with no host-side state that changes from step to step (capturable)."""
         self.flat.zero_grad()
         engine.reset_pending_backward()
-        if self.mode == "bt" and self.L == 0:
+        masked = self.mode == "mae" or bool(getattr(self.cfg, "mask", False))
+        mr = (self.cfg.mask_ratio if mask_ratio is None else mask_ratio) if masked else 0
+        recon_on = self.mode == "mae" or bool(getattr(self.cfg, "masked_recon", False))
+        if self.mode == "bt" and self.L == 0 and not masked and not recon_on:
             z = self.online(views, ncrops=2)
             z1, z2 = z.chunk(2)
             loss = self.criterion.forward_loss(z1, z2)
-        elif self.mode == "bt":
+        elif self.mode == "bt" and not masked and not recon_on:
             # main.py:86-119: teacher = model(images[:1], ncrops=1), student = model(images[1:], ncrops=L+1).  The two global views share
             # one encoder pass here (the encoder has no batch statistics and the head runs its BatchNorm per crop chunk, model.py:26-31,
             # in the same order: view 1, view 2, locals), the 16-wide local crops go through as their own width group
@@ -471,17 +476,26 @@ class BarlowTwinsTrainer:
             t, s1 = z.chunk(2)
             sl = self.online(views[2:], ncrops=self.L)
             loss = self.criterion(torch.cat([s1, sl]), t, ngcrops_each=1)
-        elif self.mode == "mae":
-            t, recon = self.online(views[:1], ncrops=1, mask_ratio=self.cfg.mask_ratio if mask_ratio is None else mask_ratio, masked_recon=True)
+        elif self.mode in ("bt", "mae"):
+            # main.py:69-125 with `--mask` [--masked_recon]: ONLY the teacher's view is masked (and, with masked_recon, decoded: its
+            # reconstruction loss is added, :119-122); mode 'mae' = these two flags forced on (BASELINE config 5)
+            out = self.online(views[:1], ncrops=1, mask_ratio=mr, masked_recon=recon_on)
+            t, recon = out if recon_on else (out, None)
             st = self.online(views[1:], ncrops=1 + self.L)
-            loss = self.criterion(st, t, ngcrops_each=1) + recon
+            loss = self.criterion(st, t, ngcrops_each=1)
+            if recon is not None:
+                loss = loss + recon
         else:
+            # main_bt_byol.py:79-114: `--mask` masks BOTH views of the online encoder (:83-88), the target sees them whole (:97-101)
             self.flat_pred.zero_grad()
-            o = self.online(views[:2], ncrops=2)
+            out = self.online(views[:2], ncrops=2, mask_ratio=mr, masked_recon=recon_on) if (masked or recon_on) else self.online(views[:2], ncrops=2)
+            o, recon = out if recon_on else (out, None)
             o = self.predictor(o, ncrops=1)
             with torch.no_grad():
                 t = self.target(views, ncrops=2)
             loss = self.criterion(o, t, ngcrops_each=2)
+            if recon is not None:
+                loss = loss + recon                              # main_bt_byol.py:112-114
         ops.count_nonfinite(loss.detach().reshape(1), self._nonfinite)
         if self.mode == "byol":
             # before the optimiser step (main_bt_byol.py:121-126); behind the finite-loss gate like the optimiser (:116-118)
@@ -509,8 +523,9 @@ class BarlowTwinsTrainer:
             return
         if self._steps < 1:
             raise RuntimeError("enable_graph(): run at least one eager step first (workspaces and weight copies are allocated lazily)")
-        if self.mode == "mae":
-            raise NotImplementedError("graph capture of mode 'mae' is not supported: its random masking draws from the host-visible generator")
+        if self.mode == "mae" or getattr(self.cfg, "mask", False) or getattr(self.cfg, "masked_recon", False):
+            raise NotImplementedError("graph capture with random masking is not supported: the masking indices come from torch's generator "
+                                      "and a host-side argsort per step")
         if self.L:
             raise NotImplementedError("graph capture with local crops is not supported (the static input buffers hold the two global views)")
         pair = torch.empty(2, self.B, 1, self.cfg.n_mels, self.cfg.crop_frames, device=self.device)

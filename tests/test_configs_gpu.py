@@ -314,6 +314,45 @@ def test_trainer_local_crops_step_vs_oracle(dev):
         BarlowTwinsTrainer(cfg, dev, mode="byol", batch_per_rank=B, clip_samples=15200, seed=0, from_waveform=False)
 
 
+def test_trainer_honours_mask_flags_of_both_drivers(dev):
+    """`--mask [--masked_recon]` as the two drivers apply them: main.py:69-125 masks (and reconstructs) the TEACHER's view only -- the
+    trainer's mode 'bt' with those flags is exactly its mode 'mae' (BASELINE config 5), bit for bit on the same generator state;
+    main_bt_byol.py:79-114 masks both views of the ONLINE encoder, the target sees them whole -- with mask_ratio 0 that is the unmasked
+    step bit for bit, with 0.25 a different, finite loss with every gradient alive (reconstruction loss added when asked)."""
+    g = torch.Generator().manual_seed(9)
+    views = [torch.randn(8, 1, 64, 96, generator=g).to(dev), torch.randn(8, 1, 64, 96, generator=g).to(dev)]
+    kw = dict(model_type="vit_tiny", batch_size=8, crop_frames=96, projector_hidden_dim=256, projector_out_dim=64)
+
+    def step(mode, seed=123, mask_ratio=None, **flags):
+        cfg = hp.make_args(**kw, **flags)
+        tr = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=8, clip_samples=15200, seed=0, from_waveform=False)
+        torch.manual_seed(seed)                      # the masking noise comes from torch's generator (models/mae.py:332)
+        loss = float(tr.step_views(views, mask_ratio=mask_ratio))
+        torch.cuda.synchronize()
+        return loss, tr
+    l_mae, t_mae = step("mae", masked_recon=True, mask=True, mask_ratio=0.5)
+    l_bt, t_bt = step("bt", masked_recon=True, mask=True, mask_ratio=0.5)
+    assert l_mae == l_bt and torch.equal(t_mae.flat.grads, t_bt.flat.grads) and torch.equal(t_mae.flat.params, t_bt.flat.params)
+    l_plain, t_plain = step("bt")
+    l_mask, t_mask = step("bt", mask=True, mask_ratio=0.5)        # masking without the decoder
+    assert np.isfinite(l_mask) and l_mask != l_plain and l_mask != l_bt
+    byol = dict(stop_gradient=True, predictor=True)
+    l0, t0 = step("byol", **byol)
+    l0m, t0m = step("byol", mask=True, mask_ratio=0.0, **byol)
+    assert l0 == l0m and torch.equal(t0.flat.grads, t0m.flat.grads)
+    l25, t25 = step("byol", mask=True, mask_ratio=0.25, **byol)
+    assert np.isfinite(l25) and l25 != l0
+    bad = [k for k, gr in flat_grads(t25).items() if not (torch.isfinite(gr).all() and float(gr.abs().max()) > 0)]
+    assert not bad, bad[:5]
+    l25r, t25r = step("byol", mask=True, mask_ratio=0.25, masked_recon=True, **byol)
+    # + reconstruction loss (main_bt_byol.py:112-114): the decoder takes part (a different initialisation sequence: losses not comparable)
+    gr = flat_grads(t25r)
+    assert np.isfinite(l25r) and float(gr["backbone.encoder.encoder.mask_token"].abs().max()) > 0
+    assert float(gr["backbone.encoder.encoder.decoder_pred.weight"].abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        t25.enable_graph()
+
+
 def test_step_through_the_dispatcher_equals_direct(dev):
     """the same three steps with every kernel call routed through `torch.ops.ssl_audio.*` (torch.library custom
     operators: ops.route_through_dispatcher) and with the direct ctypes calls -- same kernels, so bit-identical losses, gradients and
