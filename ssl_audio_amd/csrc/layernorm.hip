@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dy arrives as bf16 (from a dgrad GEMM) or fp32 (from the loss side).  Each lane owns fixed columns, so its
 // dgamma/dbeta partials stay in registers over all rows the block visits; one LDS reduce + a workspace row at the end.
 template <typename DY, int MAXV, int RPW>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256, (MAXV <= 4 ? 4 : 1)) void ln_bwd_kernel(const DY* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres, int64_t lddres,
                                                      float* __restrict__ dx_f32, bf16_t* __restrict__ dx_bf16, int64_t lddx,
@@ -109,7 +109,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
     const int rowc = live ? row : 0;
     const float mean = mean_in[rowc], rstd = rstd_in[rowc];
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)rowc * ldx);
-    float4 xh[MAXV], gd[MAXV];
+    // From four float4 columns per lane on (D = 1024, ViT-L) a row keeps dy between the two sweeps as the two dwords it was loaded as
+    // (bf16) and re-reads gamma from L1 in the second sweep: 6 instead of 8 registers per column take the kernel from 136 to 124
+    // registers, i.e. from three to four waves per SIMD -- 259 -> 185 us at [63 744, 1024].  Narrower rows already run four waves per
+    // SIMD and the recomputation costs them 2 - 7 % (measured), so they keep the fp32 product.
+    constexpr bool PACKED = sizeof(DY) == 2 && MAXV >= 4;
+    float4 xh[MAXV], gd[PACKED ? 1 : MAXV];
+    bf16x4 dh[PACKED ? MAXV : 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -127,9 +133,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
         ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
-        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+        const float4 gdi = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        if constexpr (PACKED) dh[i] = reinterpret_cast<const bf16x4*>(dy + (int64_t)row * lddy)[c];
+        else gd[i] = gdi;
+        s1 += (gdi.x + gdi.y) + (gdi.z + gdi.w);
+        s2 += (gdi.x * xh[i].x + gdi.y * xh[i].y) + (gdi.z * xh[i].z + gdi.w * xh[i].w);
       }
     }
     const float m1 = group_sum<LPR>(s1) / (float)D, m2 = group_sum<LPR>(s2) / (float)D;
@@ -137,11 +145,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DY* __restrict__ dy, 
     for (int i = 0; i < MAXV; ++i) {
       const int c = sub + i * LPR;
       if (c < nv && live) {
+        float4 gdi;
+        if constexpr (PACKED) {
+          const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+          gdi = make_float4(bf2f(dh[i][0]) * g.x, bf2f(dh[i][1]) * g.y, bf2f(dh[i][2]) * g.z, bf2f(dh[i][3]) * g.w);
+        } else {
+          gdi = gd[i];
+        }
         float4 o;
-        o.x = rstd * (gd[i].x - m1 - xh[i].x * m2);
-        o.y = rstd * (gd[i].y - m1 - xh[i].y * m2);
-        o.z = rstd * (gd[i].z - m1 - xh[i].z * m2);
-        o.w = rstd * (gd[i].w - m1 - xh[i].w * m2);
+        o.x = rstd * (gdi.x - m1 - xh[i].x * m2);
+        o.y = rstd * (gdi.y - m1 - xh[i].y * m2);
+        o.z = rstd * (gdi.z - m1 - xh[i].z * m2);
+        o.w = rstd * (gdi.w - m1 - xh[i].w * m2);
         if (dres) {
           const float4 r = reinterpret_cast<const float4*>(dres + (int64_t)row * lddres)[c];
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
