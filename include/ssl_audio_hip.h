@@ -88,6 +88,10 @@ int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
  * the data gradients dX = dY W run in the forward (k-contiguous x k-contiguous) operand layout, measured 6-16 % faster than reading W
  * k-strided; refreshed once per optimiser step. */
 int sa_transpose_bf16(const void* src_bf16, int32_t R, int32_t C, void* dst_bf16, void* stream);
+/* the same for n matrices in ONE launch (all Linear weights after an optimiser step; ABI v5).  desc_dev: device array [n][4] of int64
+ * {src pointer, dst pointer, R | (int64)C << 32, index of the matrix' first 64 x 64 tile among all tiles}, matrices in tile order;
+ * n_tiles = sum over the matrices of ceil(R / 64) * ceil(C / 64). */
+int sa_transpose_bf16_batch(const int64_t* desc_dev, int32_t n_matrices, int32_t n_tiles, void* stream);
 /* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients of nn.Linear, models/mae.py:125-131,155 backward);
  * accumulate != 0 adds.  ws: scratch of sa_colsum_workspace_bytes(M, N) bytes -- row slabs store their partial sums there and a
  * second launch adds them in slab order (bit-reproducible; ABI v5).  ws == NULL: one float atomic per column per block instead

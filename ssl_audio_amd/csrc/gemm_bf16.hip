@@ -1220,9 +1220,8 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
 
 namespace {
 // dst[c][r] = src[r][c] for a bf16 [R][C] matrix: 64 x 64 tiles through LDS (padded rows: no bank conflicts), 16-byte global accesses
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int Cn, bf16_t* __restrict__ dst) {
-  __shared__ bf16_t tile[64][66];
-  const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+__device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ src, int R, int Cn, bf16_t* __restrict__ dst, int tr, int tc,
+                                               bf16_t (*tile)[66]) {
   for (int i = threadIdx.x; i < 64 * 8; i += 256) {                 // 64 rows x 8 chunks of 8 elements
     const int r = i >> 3, ch = i & 7;
     bf16x8 v;
@@ -1247,6 +1246,25 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
       for (int e = 0; e < 8; ++e) if (tr + ch * 8 + e < R) o[e] = v[e];
   }
 }
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int Cn, bf16_t* __restrict__ dst) {
+  __shared__ bf16_t tile[64][66];
+  transpose_tile(src, R, Cn, dst, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+
+// Many matrices in ONE launch (all Linear weights after the optimiser step: 48 launches of ~5 us became one).  desc[m] = {src, dst,
+// R | C << 32, first tile of matrix m}; block b finds its matrix by a uniform scan of the (few dozen) first-tile entries.
+__global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const int64_t* __restrict__ desc, int n) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.x;
+  int m = 0;
+  while (m + 1 < n && desc[4 * (m + 1) + 3] <= b) ++m;
+  const bf16_t* src = reinterpret_cast<const bf16_t*>(desc[4 * m]);
+  bf16_t* dst = reinterpret_cast<bf16_t*>(desc[4 * m + 1]);
+  const int R = (int)(desc[4 * m + 2] & 0xFFFFFFFF), Cn = (int)(desc[4 * m + 2] >> 32);
+  const int t = b - (int)desc[4 * m + 3], tx = (Cn + 63) / 64;
+  transpose_tile(src, R, Cn, dst, (t / tx) * 64, (t % tx) * 64, tile);
+}
 }  // namespace
 
 extern "C" int sa_transpose_bf16(const void* src, int32_t R, int32_t Cn, void* dst, void* stream) {
@@ -1254,6 +1272,13 @@ extern "C" int sa_transpose_bf16(const void* src, int32_t R, int32_t Cn, void* d
   SA_CHECK_ARG(R % 8 == 0 && Cn % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "sa_transpose_bf16: 16-byte aligned rows (R, C multiples of 8)");
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cn + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, R, Cn, (bf16_t*)dst);
   SA_LAUNCH_CHECK("sa_transpose_bf16");
+  return 0;
+}
+
+extern "C" int sa_transpose_bf16_batch(const int64_t* desc_dev, int32_t n_matrices, int32_t n_tiles, void* stream) {
+  SA_CHECK_ARG(desc_dev && n_matrices > 0 && n_tiles > 0, "sa_transpose_bf16_batch: bad args");
+  hipLaunchKernelGGL(transpose_bf16_batch_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, desc_dev, n_matrices);
+  SA_LAUNCH_CHECK("sa_transpose_bf16_batch");
   return 0;
 }
 

@@ -107,6 +107,36 @@ class _Bf16TransposedCache:
         return ent[1]
 
 
+    def refresh_all(self, owner=None):
+        """Rebuild the transposed copies this cache holds (`owner`: only those of the parameters whose ids it contains -- one flat
+        optimiser state's) in one launch (sa_transpose_bf16_batch) -- called by the flat optimiser step
+        right after it rewrote the weights, so that the next backward's get() finds all of them fresh instead of issuing one ~5 us
+        launch per Linear (48 per ViT step).  Entries created later (first use) are transposed on their own once."""
+        live = [(k, e) for k, e in self._c.items() if e[2]() is not None and (owner is None or k in owner)]
+        if not live:
+            return
+        tag = id(owner) if owner is not None else 0
+        cache = self.__dict__.setdefault("_batch", {})
+        rows, sig, tile0 = [], [], 0
+        for k, e in live:
+            p = e[2]()
+            w16 = BF16_WEIGHTS.get(p)
+            if not w16.is_contiguous() or e[1].shape != (w16.shape[1], w16.shape[0]):
+                return                                           # (a reshaped weight: leave it to get())
+            R, Cn = w16.shape
+            rows.append((w16.data_ptr(), e[1].data_ptr(), R | (Cn << 32), tile0))
+            sig.append((w16.data_ptr(), e[1].data_ptr(), R, Cn))
+            tile0 += ((R + 63) // 64) * ((Cn + 63) // 64)
+        sig = tuple(sig)
+        if cache.get(tag, (None,))[0] != sig:                    # descriptor table: built once per set of weights
+            cache[tag] = (sig, torch.tensor(rows, dtype=torch.int64).to(live[0][1][1].device), tile0)
+        ops.transpose_bf16_batch(cache[tag][1], cache[tag][2])
+        for k, e in live:
+            p = e[2]()
+            w16 = BF16_WEIGHTS.get(p)
+            self._c[k] = ((p._version, BF16_WEIGHTS._manual.get(k, 0), WEIGHT_EPOCH[0], w16.data_ptr()), e[1], e[2])
+
+
 BF16_WEIGHTS_T = _Bf16TransposedCache()
 DGRAD_NT = os.environ.get("SA_DGRAD_NT", "1") != "0"      # data gradients against the transposed weight copies (0: k-strided weights, NN)
 

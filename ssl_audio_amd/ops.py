@@ -194,6 +194,13 @@ def transpose_bf16(src, dst=None):
     return dst
 
 
+def transpose_bf16_batch(desc, n_tiles):
+    """desc: int64 [n, 4] on the device ({src ptr, dst ptr, R | C << 32, first tile}); one launch transposes all n matrices."""
+    if desc.dtype != torch.int64 or desc.dim() != 2 or desc.shape[1] != 4 or not desc.is_cuda or not desc.is_contiguous():
+        raise ValueError("transpose_bf16_batch: desc must be a contiguous int64 [n, 4] GPU tensor")
+    check(lib().sa_transpose_bf16_batch(_p(desc), desc.shape[0], int(n_tiles), _stream()), "sa_transpose_bf16_batch")
+
+
 def cast_bf16(src, dst=None):
     _req(src, F32, "src")
     src = src.contiguous()

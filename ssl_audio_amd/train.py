@@ -86,6 +86,7 @@ class FlatState:
         ops.cast_bf16(self.params, self.params_bf16)
         self.bind_bf16()
         self.step_count = 0
+        self._param_ids = frozenset(id(p) for _, p in self.order)
         # {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)} per parameter group, read by the AdamW launches from DEVICE memory: what changes from step to
         # step is data, not a kernel argument, so a captured step (HIP graph) replays with the current values.  Staged through pinned host
         # memory by one small async copy per step.
@@ -129,6 +130,7 @@ class FlatState:
             ops.adamw_step_dev(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], self.hyper[1], betas[0], betas[1], eps, 0.0,
                                grad_scale, self.params_bf16[nd:nt], skip_flag)
         engine.WEIGHT_EPOCH[0] += 1
+        engine.BF16_WEIGHTS_T.refresh_all(self._param_ids)   # this state's transposed weight copies (the dgrad operands) in one launch
 
     def adamw(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, lr_nodecay=None):
         """One AdamW step: a launch for the decayed range (lr, wd) and one for the un-decayed range (lr_nodecay or lr, no decay) -- the
@@ -142,6 +144,7 @@ class FlatState:
             ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr if lr_nodecay is None else lr_nodecay, betas[0], betas[1], eps, 0.0,
                            self.step_count, grad_scale, self.params_bf16[nd:nt])
         engine.WEIGHT_EPOCH[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
+        engine.BF16_WEIGHTS_T.refresh_all(self._param_ids)   # ... and rebuilt here, all of this state's in one launch
 
     # ------------------------------------------------------------------ checkpoint / resume (main_bt_byol.py:492-503, utils/utils.py:37-46)
     def _trainable(self):
