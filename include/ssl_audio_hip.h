@@ -93,10 +93,13 @@ int sa_transpose_bf16(const void* src_bf16, int32_t R, int32_t C, void* dst_bf16
  * n_tiles = sum over the matrices of ceil(R / 64) * ceil(C / 64). */
 int sa_transpose_bf16_batch(const int64_t* desc_dev, int32_t n_matrices, int32_t n_tiles, void* stream);
 /* column sums of a bf16 [M][N] matrix into fp32 out[N] (bias gradients of nn.Linear, models/mae.py:125-131,155 backward);
- * accumulate != 0 adds.  ws: scratch of sa_colsum_workspace_bytes(M, N) bytes -- row slabs store their partial sums there and a
- * second launch adds them in slab order (bit-reproducible; ABI v5).  ws == NULL: one float atomic per column per block instead
- * (exact only up to the fp32 rounding of an arbitrary summation order). */
-int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, void* stream);
+ * accumulate != 0 adds.  ws: scratch of n_ranges x sa_colsum_workspace_bytes(M, N) bytes -- row slabs store their partial sums there
+ * and a second launch adds them in slab order (bit-reproducible; ABI v5).  ws == NULL: one float atomic per column per block instead
+ * (exact only up to the fp32 rounding of an arbitrary summation order).  n_ranges > 1: the same for the column ranges
+ * [z * range_stride, z * range_stride + N) of x, z < n_ranges, into out + z * range_stride, in the same launches (q and v bias
+ * gradients out of the packed dqkv: models/mae.py:125-128). */
+int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, int32_t n_ranges,
+                   int64_t range_stride, void* stream);
 int64_t sa_colsum_workspace_bytes(int32_t M, int32_t N);
 
 

@@ -40,7 +40,7 @@ _SIGNATURES = {
     "sa_cast_f32_to_bf16": [P, P, I64, P],
     "sa_transpose_bf16": [P, I32, I32, P, P],
     "sa_transpose_bf16_batch": [P, I32, I32, P],
-    "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P, P],
+    "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P, I32, I64, P],
     "sa_colsum_workspace_bytes": [I32, I32],
     "sa_layernorm_fwd": [P, I64, P, P, P, P, I64, P, P, I32, I32, F32, P],
     "sa_layernorm_bwd": [P, I32, I64, P, I64, P, P, P, P, I64, P, P, I64, P, P, P, P, I32, I32, P],

@@ -916,8 +916,10 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 
 // column sums: block handles 64 columns x a slab of rows; 256 threads = 4 row-phases x 64 columns
 __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out, int rows_per_block,
-                                   float* __restrict__ ws) {
+                                   float* __restrict__ ws, int64_t range_stride) {
   __shared__ float red[4][64];
+  x += blockIdx.z * range_stride; out += blockIdx.z * range_stride;          // column range z of the same matrix (q / v bias gradients)
+  if (ws) ws += (int64_t)blockIdx.z * gridDim.y * N;
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int ph = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block;
@@ -938,8 +940,10 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int
 // so every load is a full-line 16-byte access; partial sums meet in LDS and leave as one atomic per column per block -- or, with a
 // workspace, as one plain store per column per block (ws[row slab][N]; a second launch adds the slabs in order: bit-reproducible).
 __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __restrict__ x, int64_t ld, int M, int N, float* __restrict__ out,
-                                                              int rows_per_block, float* __restrict__ ws) {
+                                                              int rows_per_block, float* __restrict__ ws, int64_t range_stride) {
   __shared__ float red[8][256 + 8];
+  x += blockIdx.z * range_stride; out += blockIdx.z * range_stride;          // column range z of the same matrix (q / v bias gradients)
+  if (ws) ws += (int64_t)blockIdx.z * gridDim.y * N;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int col = blockIdx.x * 256 + tx * 8;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -979,8 +983,9 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const bf16_t* __re
 namespace {
 // out[n] += sum over the rows of ws[rows][N]; 16 waves split the rows, lanes are columns
 __global__ __launch_bounds__(1024) void colsum_ws_reduce_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out,
-                                                                int assign = 0) {
+                                                                int assign = 0, int64_t range_stride = 0) {
   __shared__ float red[16][64];
+  ws += (int64_t)blockIdx.y * rows * N; out += blockIdx.y * range_stride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   float acc = 0.f;
@@ -1299,41 +1304,49 @@ extern "C" int64_t sa_colsum_workspace_bytes(int32_t M, int32_t N) {
   return (M > 0 && N > 0) ? slabs * N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, void* stream) {
-  SA_CHECK_ARG(x && out && M > 0 && N > 0, "sa_colsum_bf16: bad args");
-  // ws (sa_colsum_workspace_bytes): every block stores its row slab's partial sums and a second launch adds the slabs in slab order
-  // -- bit-reproducible, and no float atomic anywhere; ws == NULL: one float atomic per column per block (order-dependent rounding)
+extern "C" int sa_colsum_bf16(const void* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, float* ws, int32_t n_ranges,
+                              int64_t range_stride, void* stream) {
+  SA_CHECK_ARG(x && out && M > 0 && N > 0 && n_ranges >= 1 && (n_ranges == 1 || range_stride >= N), "sa_colsum_bf16: bad args");
+  // ws (sa_colsum_workspace_bytes x n_ranges): every block stores its row slab's partial sums and a second launch adds the slabs in slab
+  // order -- bit-reproducible, and no float atomic anywhere; ws == NULL: one float atomic per column per block (order-dependent rounding).
+  // n_ranges > 1: the same sums for the column ranges [z * range_stride, z * range_stride + N) of x into out + z * range_stride, in the
+  // same two launches (the q and v bias gradients out of the packed dqkv, two d-wide ranges 2 d apart in both the matrix and the
+  // [q | 0 | v] bias layout).
   if (!accumulate && !ws) {
-    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, (hipStream_t)stream) != hipSuccess) {
-      sa_set_error("sa_colsum_bf16: memset failed");
-      return 2;
-    }
+    for (int z = 0; z < n_ranges; ++z)
+      if (hipMemsetAsync(out + z * range_stride, 0, sizeof(float) * (size_t)N, (hipStream_t)stream) != hipSuccess) {
+        sa_set_error("sa_colsum_bf16: memset failed");
+        return 2;
+      }
   }
   int gy;
-  if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0) {
+  if ((N & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0 && (range_stride & 7) == 0) {
     const int gx = (N + 255) / 256;
     // atomic form: two blocks per CU -- every block ends with one atomic per column, and those, not the 98 MB read, set the time beyond
     // that (measured on [63744, 768]: 512 blocks 18 us, 1024: 20, 2048: 24, 4096: 30); the workspace form ends in plain stores
-    gy = ((ws ? 1024 : 512) + gx - 1) / gx;
+    gy = ((ws ? 1024 : 512) / n_ranges + gx - 1) / gx;
     const int max_gy = (M + 63) / 64;
     if (gy > max_gy) gy = max_gy;
     if (gy > 1024) gy = 1024;
     const int rows_per_block = (((M + gy - 1) / gy) + 7) / 8 * 8;
     gy = (M + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block, ws);
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3(gx, gy, n_ranges), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block,
+                       ws, range_stride);
   } else {
     const int gx = (N + 63) / 64;
-    gy = (2048 + gx - 1) / gx;
+    gy = (2048 / n_ranges + gx - 1) / gx;
     const int max_gy = (M + 63) / 64;
     if (gy > max_gy) gy = max_gy;
     if (gy > 1024) gy = 1024;
     const int rows_per_block = (M + gy - 1) / gy;
     gy = (M + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block, ws);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy, n_ranges), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, M, N, out, rows_per_block, ws,
+                       range_stride);
   }
   SA_LAUNCH_CHECK("sa_colsum_bf16");
   if (ws) {
-    hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, gy, N, out, accumulate ? 0 : 1);
+    hipLaunchKernelGGL(colsum_ws_reduce_kernel, dim3((N + 63) / 64, n_ranges), dim3(1024), 0, (hipStream_t)stream, ws, gy, N, out, accumulate ? 0 : 1,
+                       range_stride);
     SA_LAUNCH_CHECK("sa_colsum_bf16(reduce)");
   }
   return 0;

@@ -305,8 +305,7 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv)
     # qkv
     _wgrad(dqkv, h1, g.wqkv)
-    ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
-    ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
+    ops.colsum_qv(dqkv, d, g.qb, g.vb)
     dh1 = dao
     wqb, wqk = _dgrad_w(p.wqkv)
     ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)
@@ -381,8 +380,7 @@ def block_backward_cls(dx3, dx3_16, p, g, H, N, saved, prev_b2=None):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv, n_query=1)
     _wgrad(dqkv, h1, g.wqkv)
-    ops.colsum_bf16(dqkv[:, :d], g.qb, accumulate=True)
-    ops.colsum_bf16(dqkv[:, 2 * d:], g.vb, accumulate=True)
+    ops.colsum_qv(dqkv, d, g.qb, g.vb)
     dh1 = dao
     wqb, wqk = _dgrad_w(p.wqkv)
     ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)

@@ -210,12 +210,25 @@ def cast_bf16(src, dst=None):
     return dst
 
 
-def colsum_bf16(x, out, accumulate=False):
+def colsum_bf16(x, out, accumulate=False, n_ranges=1, range_stride=0):
+    """out[n] (+)= sum_m x[m][n].  n_ranges > 1: x is the first column range (a [M, N] view) of a wider matrix; the ranges z * range_stride
+    columns further on are summed into out + z * range_stride by the same launches."""
     M, N, ld = _rows(_req(x, BF16, "x"), "x")
     # SA_DETERMINISTIC (default on): slab partials through a workspace, added in slab order -- no float atomics, bit-reproducible
-    ws = _p(_workspace(lib().sa_colsum_workspace_bytes(M, N), x.device, "colsum")) if DETERMINISTIC_WGRAD else None
-    check(lib().sa_colsum_bf16(_p(x), ld, M, N, _p(_req(out, F32, "out")), int(accumulate), ws, _stream()), "sa_colsum_bf16")
+    ws = _p(_workspace(n_ranges * lib().sa_colsum_workspace_bytes(M, N), x.device, "colsum")) if DETERMINISTIC_WGRAD else None
+    check(lib().sa_colsum_bf16(_p(x), ld, M, N, _p(_req(out, F32, "out")), int(accumulate), ws, int(n_ranges), int(range_stride), _stream()),
+          "sa_colsum_bf16")
     return out
+
+
+def colsum_qv(dqkv, d, gq, gv):
+    """q and v bias gradients (models/mae.py:125-128: k's bias is fixed at zero) out of the packed dqkv [M, 3 d]: ONE pair of launches when
+    the two gradient buffers sit 2 d apart like the columns do (the flat [q | 0 | v] layout of train.FlatState), else two."""
+    if gv.data_ptr() == gq.data_ptr() + 8 * d and gq.is_contiguous() and gv.is_contiguous():
+        colsum_bf16(dqkv[:, :d], gq.view(-1), accumulate=True, n_ranges=2, range_stride=2 * d)
+    else:
+        colsum_bf16(dqkv[:, :d], gq, accumulate=True)
+        colsum_bf16(dqkv[:, 2 * d:], gv, accumulate=True)
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

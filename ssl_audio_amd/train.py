@@ -431,7 +431,7 @@ class BarlowTwinsTrainer:
         if self.mask_ratio_schedule is not None:
             return float(self.mask_ratio_schedule[iteration])
         if getattr(self.cfg, "random_mask_ratio", False):
-            if self.mode == "byol":                              # main_bt_byol.py:70-72: fixed U(0.02, 0.2)
+            if getattr(self, "mode", None) == "byol":            # main_bt_byol.py:70-72: fixed U(0.02, 0.2)
                 return utils.generate_random(l=0.02, h=0.2, p=0.5)
             return utils.generate_random(l=0.05, h=self.cfg.mask_beta, p=0.5)
         return self.cfg.mask_ratio

@@ -41,10 +41,16 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
         out_bf16.copy_(d.to(BF16))
 
 
-def colsum_bf16(x, out, accumulate=False):
+def colsum_bf16(x, out, accumulate=False, n_ranges=1, range_stride=0):
+    assert n_ranges == 1
     s = x.float().sum(0)
     out.add_(s) if accumulate else out.copy_(s)
     return out
+
+
+def colsum_qv(dqkv, d, gq, gv):
+    colsum_bf16(dqkv[:, :d], gq, accumulate=True)
+    colsum_bf16(dqkv[:, 2 * d:], gv, accumulate=True)
 
 
 def axpy(y, x, a=1.0):

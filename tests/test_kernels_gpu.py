@@ -180,6 +180,21 @@ def test_cast_and_colsum(dev):
     assert rel_err(out, bf(x).double().sum(0)) < 1e-5
     ops.colsum_bf16(y, out, accumulate=True)
     assert rel_err(out, 2 * bf(x).double().sum(0)) < 1e-5
+    # two column ranges of one packed matrix in the same launches (q / v bias gradients out of dqkv; models/mae.py:125-128): both the
+    # vectorised (d % 8 == 0) and the scalar kernel, ordered (workspace) and atomic forms, gap columns of the output untouched
+    for d, M in ((192, 5000), (100, 777)):
+        dq = bf(rnd((M, 3 * d), 14)).to(dev)
+        ref = dq.double().cpu().sum(0)
+        for det in (True, False):
+            ops.DETERMINISTIC_WGRAD, keep = det, ops.DETERMINISTIC_WGRAD
+            g3 = torch.full((3 * d,), 7.0, device=dev)
+            ops.colsum_qv(dq, d, g3[:d], g3[2 * d:])
+            ops.DETERMINISTIC_WGRAD = keep
+            assert rel_err(g3[:d], 7.0 + ref[:d]) < 1e-5 and rel_err(g3[2 * d:], 7.0 + ref[2 * d:]) < 1e-5
+            assert torch.all(g3[d:2 * d] == 7.0)
+        gq, gv = torch.zeros(d, device=dev), torch.zeros(d, device=dev)          # separate buffers: the two-launch route
+        ops.colsum_qv(dq, d, gq, gv)
+        assert rel_err(gq, ref[:d]) < 1e-5 and rel_err(gv, ref[2 * d:]) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
