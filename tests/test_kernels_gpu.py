@@ -124,7 +124,9 @@ def test_gemm_split_k_deterministic(dev, tile256, monkeypatch):
     order, so two runs are bit-identical, the result accumulates into out_f32 like the atomic form and equals it to fp32 rounding.
     Sizes: ragged M / N tiles, a K whose last slice is short and one whose trailing slice is empty (K = 9 steps over 5 slices)."""
     monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", True)
-    for Mtok, N, K, split in [(3000, 320, 520, 5), (9 * 64, 256, 384, 5), (63744 // 8, 768, 768, 7)]:
+    # ... and many thin slices (>= 16: the four-waves-per-column-group form of the reduce, slice counts 17 / 42 leave ragged tails per wave)
+    for Mtok, N, K, split in [(3000, 320, 520, 5), (9 * 64, 256, 384, 5), (63744 // 8, 768, 768, 7), (17 * 64 * 3, 192, 200, 17),
+                              (42 * 128, 192, 768, 42)]:
         dY = bf(rnd((Mtok, N), 83)).to(dev); X = bf(rnd((Mtok, K), 84)).to(dev)
         base = torch.randn(N, K, device=dev)
         outs = []
@@ -369,6 +371,48 @@ def test_logmel(dev, L, T, start):
     ref = ofe.crop_pad_normalize(ofe.logmel(wave.numpy()), T, start, -0.8294, 4.6230)
     d = np.abs(out.cpu().numpy()[:, 0] - ref)
     assert out.shape == (3, 1, 64, T)
+    assert d.max() < 2e-3, d.max()
+
+
+def test_logmel_many_groups(dev):
+    """More 16-frame groups than the persistent kernel has workgroups (3 per CU): every workgroup walks several (clip, group) pairs,
+    the last group of a clip is ragged (101 frames = 6 x 16 + 5) and the first frame of the next pair is prefetched across the boundary."""
+    from oracle import frontend as ofe
+    n = 3 * torch.cuda.get_device_properties(0).multi_processor_count // 7 + 9
+    wave = synth_wave(n, 16000, 31)
+    out = fe.MelSpectrogram()(wave.to(dev), crop_frames=101, start=0, norm_stats=(-0.8294, 4.6230))
+    ref = ofe.crop_pad_normalize(ofe.logmel(wave.numpy()), 101, 0, -0.8294, 4.6230)
+    d = np.abs(out.cpu().numpy()[:, 0] - ref)
+    assert d.max() < 2e-3, d.max()
+
+
+@pytest.mark.parametrize("bank", ["wide", "sparse"])
+def test_logmel_other_filter_banks(dev, bank):
+    """sa_logmel_fwd takes the filter bank as a table (per band: first bin, length, weights): a bank whose 16-band groups cover more bins
+    than the kernel holds weights for in registers ("wide": 60-72 bins per band, the one-product-at-a-time path) and one that leaves whole
+    groups empty ("sparse": 8 bands of 4 bins, 56 bands of none -> log(eps)), against W . |STFT|^2 from the oracle's power spectrogram."""
+    from oracle import frontend as ofe
+    rng = np.random.RandomState(5)
+    if bank == "wide":
+        lo = (4 + 7 * np.arange(64)).astype(np.int32)
+        ln = np.minimum(60 + 3 * (np.arange(64) % 5), 513 - lo).astype(np.int32)
+    else:
+        lo = np.where(np.arange(64) < 8, 10 + 5 * np.arange(64), 0).astype(np.int32)
+        ln = np.where(np.arange(64) < 8, 4, 0).astype(np.int32)
+    maxlen = int(ln.max())
+    w = np.zeros((maxlen, 64))
+    dense = np.zeros((64, 513))
+    for m in range(64):
+        w[:ln[m], m] = rng.rand(ln[m]) / max(int(ln[m]), 1)
+        dense[m, lo[m]:lo[m] + ln[m]] = w[:ln[m], m].astype(np.float32)
+    wave = synth_wave(2, 16000, 37)
+    tb = dict(fe.build_tables(dev, n_fft=1024, n_mels=64, f_min=60.0, f_max=7800.0, sample_rate=16000, win_length=1024))
+    tb["mel_weights"] = torch.tensor(w, dtype=torch.float32, device=dev)
+    tb["mel_lo"], tb["mel_len"] = torch.tensor(lo, device=dev), torch.tensor(ln, device=dev)
+    out = torch.empty(2, 64 * 101, device=dev)
+    ops.logmel_fwd(wave.to(dev), tb, out, 101, 0, 0.0, 1.0, 160)
+    ref = np.log(np.einsum("mk,nkt->nmt", dense, ofe.power_spectrogram(wave.numpy())) + np.finfo(np.float32).eps)
+    d = np.abs(out.view(2, 64, 101).cpu().numpy() - ref)
     assert d.max() < 2e-3, d.max()
 
 
