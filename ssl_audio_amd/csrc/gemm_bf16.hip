@@ -1040,10 +1040,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *o = t;
 }
 
-// the same sum for many thin slices (a narrow weight gradient split 40 - 128 ways): the four waves of a block take every fourth slice of
-// 64 float4 columns, their partials meet in LDS and are added in wave order -- a fixed order, and 4 x the loads in flight
-__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __restrict__ ws, int nslice, int M, int N, float* __restrict__ out, int64_t ldo) {
-  __shared__ float4 part[4][64];
+// the same sum for many thin slices (a narrow weight gradient split 40 - 128 ways): the NW waves of a block take every NW-th slice of
+// 64 float4 columns, their partials meet in LDS and are added in wave order -- a fixed order, and NW x the loads in flight
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void splitk_reduce_wide_kernel(const float* __restrict__ ws, int nslice, int M, int N, float* __restrict__ out, int64_t ldo) {
+  __shared__ float4 part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i4 = (int64_t)blockIdx.x * 64 + lane;
   const int n4 = N >> 2;
@@ -1054,15 +1055,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __
   float4 acc = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     int s = wave;
-    for (; s + 12 < nslice; s += 16) {
-      const float4 v0 = *reinterpret_cast<const float4*>(src + s * slice), v1 = *reinterpret_cast<const float4*>(src + (s + 4) * slice),
-                   v2 = *reinterpret_cast<const float4*>(src + (s + 8) * slice), v3 = *reinterpret_cast<const float4*>(src + (s + 12) * slice);
+    for (; s + 3 * NW < nslice; s += 4 * NW) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + s * slice), v1 = *reinterpret_cast<const float4*>(src + (s + NW) * slice),
+                   v2 = *reinterpret_cast<const float4*>(src + (s + 2 * NW) * slice), v3 = *reinterpret_cast<const float4*>(src + (s + 3 * NW) * slice);
       acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
       acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
       acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
       acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
     }
-    for (; s < nslice; s += 4) {
+    for (; s < nslice; s += NW) {
       const float4 v = *reinterpret_cast<const float4*>(src + s * slice);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __
   float4* o = reinterpret_cast<float4*>(out + (int64_t)m * ldo + n);
   float4 t = *o;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const float4 v = part[w][lane];
     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
   }
@@ -1101,8 +1102,10 @@ extern "C" int sa_gemm_bf16(const SaGemmArgs* a, void* stream_) {
     const int64_t n4 = (int64_t)a->M * (a->N / 4);
     const int ksteps = (a->K + BK - 1) / BK, chunk = (ksteps + a->split_k - 1) / a->split_k;
     const int nslice = (ksteps + chunk - 1) / chunk;         // trailing slices with an empty K range wrote nothing
-    if (nslice >= 16)
-      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, a->splitk_ws, nslice, a->M, a->N, a->out_f32, a->ldo_f32);
+    if (nslice >= 32)
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel<8>, dim3((unsigned)((n4 + 63) / 64)), dim3(512), 0, stream, a->splitk_ws, nslice, a->M, a->N, a->out_f32, a->ldo_f32);
+    else if (nslice >= 16)
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, a->splitk_ws, nslice, a->M, a->N, a->out_f32, a->ldo_f32);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->splitk_ws, nslice, a->M, a->N, a->out_f32, a->ldo_f32);
     SA_LAUNCH_CHECK("sa_gemm_bf16(split-K reduce)");
