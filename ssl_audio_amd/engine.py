@@ -81,8 +81,23 @@ def _forget_when_dead(p, *tables):
 BF16_WEIGHTS = _Bf16Cache()
 
 # Bumped by whoever rewrites parameters with a HIP kernel (train.FlatState's optimiser step): the pinned bf16 copies are refreshed by
-# that kernel itself, anything DERIVED from them (the transposed copies below) is rebuilt on its next use.
+# that kernel itself, anything DERIVED from them (the transposed copies below) is rebuilt on its next use.  A flat state registers its own
+# counter for its parameters (PARAM_EPOCH: id(parameter) -> that one-element list), so that rewriting ONE state -- BYOL's EMA of the target
+# network, right after the online network's optimiser step rebuilt its transposed copies -- does not mark every other state's copies stale
+# (45 single-matrix transposes per BYOL step); WEIGHT_EPOCH is the counter of parameters no state owns.
 WEIGHT_EPOCH = [0]
+PARAM_EPOCH = {}
+
+
+def register_epoch(params, cell):
+    for p in params:
+        if id(p) not in PARAM_EPOCH:
+            _forget_when_dead(p, PARAM_EPOCH)
+        PARAM_EPOCH[id(p)] = cell
+
+
+def _epoch_of(key):
+    return PARAM_EPOCH.get(key, WEIGHT_EPOCH)[0]
 
 
 class _Bf16TransposedCache:
@@ -96,7 +111,7 @@ class _Bf16TransposedCache:
     def get(self, p):
         w16 = BF16_WEIGHTS.get(p)                    # current [out, in] copy (casts if the master changed)
         key = id(p)
-        ver = (p._version, BF16_WEIGHTS._manual.get(key, 0), WEIGHT_EPOCH[0], w16.data_ptr())
+        ver = (p._version, BF16_WEIGHTS._manual.get(key, 0), _epoch_of(key), w16.data_ptr())
         ent = self._c.get(key)
         if ent is None or ent[2]() is not p or ent[0] != ver:
             buf = ent[1] if ent is not None and ent[2]() is p and ent[1].shape == (w16.shape[1], w16.shape[0]) and ent[1].device == w16.device else None
@@ -134,7 +149,7 @@ class _Bf16TransposedCache:
         for k, e in live:
             p = e[2]()
             w16 = BF16_WEIGHTS.get(p)
-            self._c[k] = ((p._version, BF16_WEIGHTS._manual.get(k, 0), WEIGHT_EPOCH[0], w16.data_ptr()), e[1], e[2])
+            self._c[k] = ((p._version, BF16_WEIGHTS._manual.get(k, 0), _epoch_of(k), w16.data_ptr()), e[1], e[2])
 
 
 BF16_WEIGHTS_T = _Bf16TransposedCache()

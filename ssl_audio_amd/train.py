@@ -87,6 +87,8 @@ class FlatState:
         self.bind_bf16()
         self.step_count = 0
         self._param_ids = frozenset(id(p) for _, p in self.order)
+        self.epoch = [0]                                  # bumped whenever a kernel rewrites this state's weights (engine.PARAM_EPOCH)
+        engine.register_epoch([p for _, p in self.order], self.epoch)
         # {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)} per parameter group, read by the AdamW launches from DEVICE memory: what changes from step to
         # step is data, not a kernel argument, so a captured step (HIP graph) replays with the current values.  Staged through pinned host
         # memory by one small async copy per step.
@@ -129,7 +131,7 @@ class FlatState:
         if nt > nd:
             ops.adamw_step_dev(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], self.hyper[1], betas[0], betas[1], eps, 0.0,
                                grad_scale, self.params_bf16[nd:nt], skip_flag)
-        engine.WEIGHT_EPOCH[0] += 1
+        self.epoch[0] += 1
         engine.BF16_WEIGHTS_T.refresh_all(self._param_ids)   # this state's transposed weight copies (the dgrad operands) in one launch
 
     def adamw(self, lr, wd, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, lr_nodecay=None):
@@ -143,7 +145,7 @@ class FlatState:
         if nt > nd:
             ops.adamw_step(self.params[nd:nt], self.grads[nd:nt], self.m[nd:nt], self.v[nd:nt], lr if lr_nodecay is None else lr_nodecay, betas[0], betas[1], eps, 0.0,
                            self.step_count, grad_scale, self.params_bf16[nd:nt])
-        engine.WEIGHT_EPOCH[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
+        self.epoch[0] += 1                    # copies derived from the bf16 weights (transposed dgrad operands) are stale now
         engine.BF16_WEIGHTS_T.refresh_all(self._param_ids)   # ... and rebuilt here, all of this state's in one launch
 
     # ------------------------------------------------------------------ checkpoint / resume (main_bt_byol.py:492-503, utils/utils.py:37-46)
@@ -197,7 +199,7 @@ class FlatState:
     def refresh_from_parameters(self):
         """After load_state_dict wrote the (flat-backed) parameters: re-cast the bf16 copies the GEMMs read."""
         ops.cast_bf16(self.params, self.params_bf16)
-        engine.WEIGHT_EPOCH[0] += 1
+        self.epoch[0] += 1
 
     def ema_from(self, other, beta, skip_flag=None):
         """self = beta * self + (1 - beta) * other over all parameters (utils/utils.py:328-331), one launch (a no-op while the device word
@@ -208,7 +210,7 @@ class FlatState:
         else:
             ops.ema_update(self.params, other.params, beta)
         ops.cast_bf16(self.params, self.params_bf16)
-        engine.WEIGHT_EPOCH[0] += 1
+        self.epoch[0] += 1
 
 
 def merge_optim_state_dicts(*sds):
@@ -629,6 +631,8 @@ class _FrozenFlat:
                 engine.QKV_BIAS[id(p)] = (weakref.ref(p), self.params[off:off + 3 * n])
                 engine._forget_when_dead(p, engine.QKV_BIAS)
         ops.cast_bf16(self.params, self.params_bf16)
+        self.epoch = [0]                                  # (its own counter: an EMA step leaves the online network's transposed copies fresh)
+        engine.register_epoch([named[name] for name, _ in like.order], self.epoch)
 
     ema_from = FlatState.ema_from
     refresh_from_parameters = FlatState.refresh_from_parameters
