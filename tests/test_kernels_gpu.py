@@ -386,6 +386,24 @@ def test_logmel_many_groups(dev):
     assert d.max() < 2e-3, d.max()
 
 
+def test_logmel_full_size_properties(dev):
+    """BASELINE's frontend shape (128 clips of 10 s: 8 064 groups of 16 frames over 768 persistent workgroups), checked through properties
+    that need no oracle: (i) a clip delayed by one hop gives the same frames one column later, BIT FOR BIT away from the clip's ends (a frame's
+    arithmetic does not depend on where in a clip, a group or a workgroup's walk it sits); (ii) a gain of a shifts the un-normalised
+    log-mel by 2 ln a wherever the power is far above eps; (iii) two launches agree bit for bit."""
+    B, L, T, hop = 128, 160000, 1001, 160
+    g = torch.Generator(device=dev).manual_seed(41)
+    base = 0.1 * torch.randn(B, L + hop, device=dev, generator=g)
+    mel = fe.MelSpectrogram()
+    a = mel(base[:, hop:].contiguous(), crop_frames=T, start=0)[:, 0]          # frames of x[hop:]
+    b = mel(base[:, :L].contiguous(), crop_frames=T, start=0)[:, 0]            # frames of x[:L]: frame t + 1 sees what frame t of `a` sees
+    assert torch.equal(a[:, :, 4:T - 5], b[:, :, 5:T - 4])                     # (4 frames at each end touch the reflect padding)
+    assert torch.equal(a, mel(base[:, hop:].contiguous(), crop_frames=T, start=0)[:, 0])
+    c = mel((3.0 * base[:, hop:]).contiguous(), crop_frames=T, start=0)[:, 0]
+    assert float((c - a - 2.0 * math.log(3.0)).abs().max()) < 1e-4
+    assert torch.isfinite(a).all()
+
+
 @pytest.mark.parametrize("bank", ["wide", "sparse"])
 def test_logmel_other_filter_banks(dev, bank):
     """sa_logmel_fwd takes the filter bank as a table (per band: first bin, length, weights): a bank whose 16-band groups cover more bins
