@@ -209,10 +209,9 @@ int sa_count_nonfinite(const float* x, int64_t n, int32_t* flag, void* stream);
  * wave [n_clips][wave_stride] fp32 -> out [n_clips][64][T_out] fp32 (clip stride out_stride).  Output frame t is
  * source frame t + start; frames past the clip are the normalised zero pad.  Tables (host-built, uploaded once):
  * window [1024]; twiddle [1024][2] = (cos, -sin)(2 pi k / 1024); mel_lo/mel_len [64] = first power bin and number of bins of each
- * band; mel_weights [maxlen][64] with maxlen = max(mel_len), entry [q][m] = weight of bin mel_lo[m] + q in band m and ZERO for
- * q >= mel_len[m] (the kernel runs maxlen terms for every band, reading zero-weighted bins past a band's end -- past bin 512 a zero
- * tail: a table that is not zero-padded gives wrong mel values, and a non-finite power bin reaches every band whose padded range
- * touches it). */
+ * band (mel_lo + mel_len <= 513); mel_weights [maxlen][64] with maxlen = max(mel_len), entry [q][m] = weight of bin mel_lo[m] + q in band m (entries with
+ * q >= mel_len[m] are not read).  The 513 -> 64 projection runs on the fp32 MFMA per group of 16 bands over the bins the group's bands cover,
+ * so a non-finite power bin of a frame reaches every band of the groups whose range contains it (0 x NaN), not only the bands that weight it. */
 int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32_t n_samples, const float* window,
                   const float* twiddle, const float* mel_weights, const int32_t* mel_lo, const int32_t* mel_len, float* out,
                   int64_t out_stride, int32_t T_out, int32_t start, float mean, float stdv, int32_t hop, void* stream);
