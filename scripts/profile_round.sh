@@ -42,6 +42,7 @@ python3 scripts/bench_gemm_torch.py > $O/bench_gemm_hipblaslt.txt 2>&1
 python3 scripts/bench_attn.py > $O/bench_attn.txt 2>&1; python3 scripts/bench_attn.py 501 >> $O/bench_attn.txt 2>&1
 for f in $O/bench_gemm_block.txt $O/bench_gemm_hipblaslt.txt $O/bench_attn.txt; do tail -n 3 $f; done
 python3 scripts/bench_frontend.py > $O/bench_frontend.txt 2>&1; tail -n 2 $O/bench_frontend.txt
+bash scripts/pmc_frontend.sh $O/pmc_fe > $O/frontend_pmc.txt 2>&1; rm -rf $O/pmc_fe; head -n 3 $O/frontend_pmc.txt     # (profiles/${R}_frontend_pmc.txt = this + a reading)
 # BASELINE config 3's global batch on ONE GPU (strong-scaling anchor, ~200 GB resident), and the headline through the self-launch path
 python3 bench.py --global_batch 1024 --steps 5 --warmup 2 --no_cpu_baseline > $O/bench_vit_base_bt_10s_b1024_line.json 2> $O/bench_b1024.err || echo "b1024 failed"
 cut -c1-200 $O/bench_vit_base_bt_10s_b1024_line.json
