@@ -207,14 +207,26 @@ int sa_count_nonfinite(const float* x, int64_t n, int32_t* flag, void* stream);
 /* ------------------------------------------------------------------ log-mel frontend
  * Replaces torchaudio MelSpectrogram + log at datasets.py:39-48,115 and crop/pad/normalise at datasets.py:342-354.
  * wave [n_clips][wave_stride] fp32 -> out [n_clips][64][T_out] fp32 (clip stride out_stride).  Output frame t is
- * source frame t + start; frames past the clip are the normalised zero pad.  Tables (host-built, uploaded once):
+ * source frame t + start; frames past the clip are the normalised zero pad.
+ * Per-clip geometry (ABI v6; each array optional, device memory, [n_clips] int32; NULL = the launch-wide value), so that ONE launch does
+ * what the reference's Dataset.__getitem__ does per sample (a random crop start and a right pad of its own for every clip):
+ *   starts[b]   source frame of clip b's output frame 0 -- `start = np.random.randint(l - crop_frames)` of datasets.py:342-345 (replaces `start`);
+ *   lengths[b]  clip b's length in SAMPLES (replaces n_samples, which stays the row bound): it has 1 + lengths[b] / hop frames, the
+ *               reflect padding of the last frames mirrors at ITS end, and output frames past its last frame are the normalised zero pad
+ *               (datasets.py:346-351).  A clip of <= 512 samples cannot be reflect-padded: all of its output is the pad;
+ *   offsets[b]  first sample of clip b inside its row (default 0): the waveform-level crop `wav[start:start + unit_length]` of
+ *               datasets.py:108-112 without a copy (the frames are those of the cropped waveform, reflecting at the crop's ends).
+ *   The kernel clamps offsets[b] to [0, n_samples] and lengths[b] to [0, n_samples - offsets[b]] (no read leaves the row); 16-frame groups that
+ *   lie wholly in a clip's padding are written without any transform work.
+ * Tables (host-built, uploaded once):
  * window [1024]; twiddle [1024][2] = (cos, -sin)(2 pi k / 1024); mel_lo/mel_len [64] = first power bin and number of bins of each
  * band (mel_lo + mel_len <= 513); mel_weights [maxlen][64] with maxlen = max(mel_len), entry [q][m] = weight of bin mel_lo[m] + q in band m (entries with
  * q >= mel_len[m] are not read).  The 513 -> 64 projection runs on the fp32 MFMA per group of 16 bands over the bins the group's bands cover,
  * so a non-finite power bin of a frame reaches every band of the groups whose range contains it (0 x NaN), not only the bands that weight it. */
 int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32_t n_samples, const float* window,
                   const float* twiddle, const float* mel_weights, const int32_t* mel_lo, const int32_t* mel_len, float* out,
-                  int64_t out_stride, int32_t T_out, int32_t start, float mean, float stdv, int32_t hop, void* stream);
+                  int64_t out_stride, int32_t T_out, int32_t start, const int32_t* starts, const int32_t* lengths, const int32_t* offsets,
+                  float mean, float stdv, int32_t hop, void* stream);
 
 /* ------------------------------------------------------------------ augmentation stack (one fused launch per batch of views)
  * Replaces MixupBYOLA.forward / log_mixup_exp (augmentations.py:81-85,103-117), RandomResizeCrop.forward

@@ -175,6 +175,26 @@ class PairTransformOracle:
             crops.append(self._local(x))
         return crops
 
+    def dataset_item(self, lms, norm_stats=None):
+        """`Dataset.__getitem__` from the loaded log-mel on (datasets.py:342-358): lms [1, F, l] -> trim at
+        `start = np.random.randint(l - crop_frames)` when l > crop_frames (the GLOBAL numpy stream: the one the transform's draws come
+        from, so the crop draw precedes the clip's view draws) or right zero-pad when shorter (:346-350), normalise (:353-354), then the
+        pair transform (:356-358).  Returns (crops, start); `self.starts` keeps every start drawn."""
+        lms = np.asarray(lms, dtype=np.float64)
+        l, crop = lms.shape[-1], self.out_size[1]
+        start = 0
+        if l > crop:
+            start = int(self.np_rng.randint(l - crop))                  # datasets.py:344
+            lms = lms[..., start:start + crop]
+        elif l < crop:
+            lms = np.pad(lms, [(0, 0)] * (lms.ndim - 1) + [(0, crop - l)])
+        if norm_stats is not None:
+            lms = (lms - norm_stats[0]) / norm_stats[1]
+        if not hasattr(self, "starts"):
+            self.starts = []
+        self.starts.append(start)
+        return self(lms), start
+
 
 def mix_gaussian_noise(lms, lambd, normal):
     """MixGaussianNoise.forward (augmentations.py:132-141) with the draws made explicit: lambd = ratio * np.random.rand(),

@@ -12,7 +12,7 @@ for _ in range(3):
     out = fe(wave, crop_frames=T, start=0, norm_stats=(-0.8294, 4.6230))
 torch.cuda.synchronize()
 o = out[:, 0].cpu()                      # [B, 64, T]
-# the kernel is persistent: workgroup i (of 3 x CUs) starts with group i of the (clip, 16-frame group) list and stamps that group's outputs
+# the kernel is persistent: workgroup i (of 3 x CUs) starts with entry i of the (16-frame group, clip) list -- group-major since round 5 -- and stamps that group's outputs
 import ctypes
 from ssl_audio_amd import ops
 n_wg = 3 * torch.cuda.get_device_properties(0).multi_processor_count
@@ -21,7 +21,7 @@ names = ["prologue(tables)", "phase1(4 frames)", "weights", "barrier1", "mfma", 
 for w in range(4):
     rows = []
     for i in range(n_wg):
-        c, b = divmod(i, gpc)
+        b, c = divmod(i, B)
         if 16 * b + 8 <= T:
             rows.append(o[c, 16 * w, 16 * b: 16 * b + 8])
     st = torch.stack(rows)

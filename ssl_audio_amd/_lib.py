@@ -104,7 +104,7 @@ _SIGNATURES = {
     "sa_ema_update_gated": [P, P, I64, F32, P, P],
     "sa_axpy_f32": [P, P, I64, F32, P],
     "sa_count_nonfinite": [P, I64, P, P],
-    "sa_logmel_fwd": [P, I64, I32, I32, P, P, P, P, P, P, I64, I32, I32, F32, F32, I32, P],
+    "sa_logmel_fwd": [P, I64, I32, I32, P, P, P, P, P, P, I64, I32, I32, P, P, P, F32, F32, I32, P],
     "sa_augment_views": [P, I64, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, F32, I32, P, P],
     "sa_normalize_batch": [P, P, I64, F32, P, F32, F32, P],
     "sa_patchify_bf16": [P, P, I32, I32, I32, I32, I32, P],

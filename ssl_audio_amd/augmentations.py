@@ -23,12 +23,27 @@ from . import ops
 EPS32 = 1.1920929e-07
 
 
-def _launch(store, clip_stride, src, mix, params, out, F_in, T_in, canvas, do_fade, noise=None):
+def _to_dev(a, dtype, dev):
+    """Host parameters -> device: lists / numpy arrays are staged through a fresh pinned block (the copy is asynchronous and the host runs
+    ahead of the stream, so a reused block could be overwritten before its copy has read it)."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=dev, dtype=dtype, non_blocking=True)
+    h = torch.as_tensor(np.asarray(a, dtype={torch.float32: np.float32, torch.int32: np.int32}[dtype]))
+    if torch.device(dev).type == "cuda":
+        h = h.pin_memory()
+    return h.to(dev, non_blocking=True)
+
+
+def _launch(store, clip_stride, src, mix, params, out, F_in, T_in, canvas, do_fade, noise=None, max_w=None):
     dev = store.device
-    p = torch.tensor(params, dtype=torch.float32).reshape(-1, 8).to(dev, non_blocking=True)
-    s = torch.tensor(src, dtype=torch.int32).to(dev, non_blocking=True)
-    m = torch.tensor(mix, dtype=torch.int32).to(dev, non_blocking=True) if mix is not None else None
-    ratio = canvas[1] / max(out.shape[-1] - 1, 1)
+    p = _to_dev(params, torch.float32, dev).reshape(-1, 8)
+    s = _to_dev(src, torch.int32, dev)
+    m = _to_dev(mix, torch.int32, dev) if mix is not None else None
+    # the kernel sizes its LDS source tile for the widest crop of the launch (include/ssl_audio_hip.h: max_w_ratio); the widest crop that was
+    # DRAWN, not the canvas: 16-wide local crops of a 10 s clip are at most 0.6 of the canvas (ADVICE r4)
+    if max_w is None:
+        max_w = float(np.asarray(params, dtype=np.float64).reshape(-1, 8)[:, 4].max()) if not isinstance(params, torch.Tensor) else canvas[1]
+    ratio = min(max_w, canvas[1]) / max(out.shape[-1] - 1, 1)
     ops.augment_views(store, clip_stride, s, m, p, out, F_in, T_in, canvas, ratio, do_fade, noise)
     return out
 
@@ -38,10 +53,13 @@ def draw_rrc_params(canvas, in_size, time_scale, freq_scale, np_rng=np.random, p
     `random`, inclusive bounds, drawn only when the canvas is larger than the crop)."""
     canvas_h, canvas_w = canvas
     src_h, src_w = in_size
-    h = int(np.clip(int(np_rng.uniform(*freq_scale) * src_h), 1, canvas_h))
-    w = int(np.clip(int(np_rng.uniform(*time_scale) * src_w), 1, canvas_w))
-    i = py_rng.randint(0, canvas_h - h) if canvas_h > h else 0
-    j = py_rng.randint(0, canvas_w - w) if canvas_w > w else 0
+    # np.random.uniform(a, b) IS a + (b - a) * random_sample() (one draw, the same two fp64 operations: checked draw for draw in
+    # tests/test_boundary.py) at a tenth of the call cost; np.clip(int(.), 1, canvas) on plain ints; randint(0, n) = randrange(n + 1)
+    rs = np_rng.random_sample
+    h = min(max(int((freq_scale[0] + (freq_scale[1] - freq_scale[0]) * rs()) * src_h), 1), canvas_h)
+    w = min(max(int((time_scale[0] + (time_scale[1] - time_scale[0]) * rs()) * src_w), 1), canvas_w)
+    i = py_rng.randrange(canvas_h - h + 1) if canvas_h > h else 0
+    j = py_rng.randrange(canvas_w - w + 1) if canvas_w > w else 0
     return i, j, h, w
 
 
@@ -235,7 +253,8 @@ class BatchedPairAugment:
         self.clips = 0           # clips processed so far
         self.store = None
         self.capacity = 0
-        self.records = []        # explicit parameters of the last batch (for parity tests)
+        self._last = None        # the last batch's draws in event order (`records` builds its dictionaries from them on demand)
+        self.starts = None       # the last batch's dataset crop starts (frames), one per clip; None when draw() was not given src_frames
 
     def _ensure_store(self, B):
         need = -(-(self.n // 2 + 1 + B) // B) * B           # multiple of B so a batch is always contiguous
@@ -253,52 +272,103 @@ class BatchedPairAugment:
         s0 = self.clips % self.capacity
         return self.store[s0:s0 + B]
 
-    def draw(self, B):
-        """Host-side sampling in the reference's RNG call order; returns src, mix, params lists ordered
-        [view0 of all clips..., view1 of all clips...] while DRAWING in event order clip0v0, clip0v1, [clip0 locals,] clip1v0, ...
-        (`self.local_draw` = (src, params) of the L * B local views, ordered [local0 of all clips..., local1 ...])."""
-        canvas = [int(s * c) for s, c in zip((self.F, self.T), self.vcs)] if self.rrc else [self.F, self.T]
-        src = [0] * (2 * B)
-        mix = [-1] * (2 * B)
-        par = [None] * (2 * B)
-        lsrc, lpar = [0] * (self.L * B), [None] * (self.L * B)
-        self.records = []
-        for b in range(B):
-            clip = self.clips + b
-            for v in range(2):
-                alpha, k, lam = 0.0, -1, 0.0
-                if self.mixup:
-                    alpha = self.ratio * self.np_rng.random_sample()
-                    c = min(self.events, self.n)
-                    if c > 0:
-                        k = int(self.np_rng.randint(c))
-                        g = self.events - c + k                       # global append index of FIFO entry k
-                        mix[v * B + b] = (g // 2) % self.capacity
-                    self.events += 1
-                if self.gnoise:
-                    lam = self.gnoise_ratio * self.np_rng.rand()      # augmentations.py:135
-                if self.rrc:
-                    i, j, h, w = draw_rrc_params(canvas, (self.F, self.T), self.scale, self.scale, self.np_rng, self.py_rng)
-                else:
-                    i, j, h, w = 0, 0, self.F, self.T
-                head, tail = (1.0 * ((2.0 * self.np_rng.rand(2)) - 1.0)) if self.rlf else (0.0, 0.0)
-                src[v * B + b] = clip % self.capacity
-                par[v * B + b] = [alpha if k >= 0 else 0.0, i, j, h, w, head, tail, lam]
-                self.records.append({"clip": clip, "view": v, "alpha": alpha, "bank_index": k, "rrc": (i, j, h, w),
-                                     "head_tail": (head, tail), "lambd": lam})
-            for l in range(self.L):                                   # utils/transforms.py:54-55: the un-mixed clip, no fade
-                i, j, h, w = draw_rrc_params((self.F, self.T), (self.F, self.T), self.local_scale, self.local_scale, self.np_rng, self.py_rng)
-                lsrc[l * B + b] = clip % self.capacity
-                lpar[l * B + b] = [0.0, i, j, h, w, 0.0, 0.0, 0.0]
-                self.records.append({"clip": clip, "local": l, "rrc": (i, j, h, w)})
-        self.local_draw = (lsrc, lpar)
-        return src, mix, par, canvas
+    @property
+    def records(self):
+        """Explicit parameters of the last batch, one dictionary per view in DRAW order (parity tests and the smoke check read them; the
+        step itself never does, so they are built on demand and cost the sampler nothing)."""
+        if self._last is None:
+            return []
+        clip0, ev, loc = self._last
+        L, out = self.L, []
+        for e, (alpha, k, i, j, h, w, head, tail, lam) in enumerate(ev):
+            out.append({"clip": clip0 + e // 2, "view": e % 2, "alpha": alpha, "bank_index": k, "rrc": (i, j, h, w), "head_tail": (head, tail),
+                        "lambd": lam})
+            if L and e % 2 == 1:
+                for l in range(L):
+                    out.append({"clip": clip0 + e // 2, "local": l, "rrc": loc[(e // 2) * L + l]})
+        return out
 
-    def __call__(self, B, out=None):
+    def draw(self, B, src_frames=None):
+        """Host-side sampling in the reference's RNG call order; returns src, mix, params (arrays ordered
+        [view0 of all clips..., view1 of all clips...]) and the canvas, while DRAWING in event order clip0v0, clip0v1, [clip0 locals,]
+        clip1v0, ...  (`self.local_draw` = (src, params) of the L * B local views, ordered [local0 of all clips..., local1 ...]).
+
+        src_frames (int, or one int per clip): frame count l of each clip's un-cropped log-mel.  The dataset's crop
+        `start = np.random.randint(l - crop_frames)` (datasets.py:342-345; drawn only when l > crop_frames) is then sampled per clip
+        BEFORE that clip's view draws -- `Dataset.__getitem__` crops, then runs the transform (:356-358) -- and left in `self.starts`
+        for the frontend launch that fills `next_slots(B)`."""
+        F, T = self.F, self.T
+        if not self.capacity:
+            self._ensure_store(B)
+        canvas = [int(s * c) for s, c in zip((F, T), self.vcs)] if self.rrc else [F, T]
+        rs, ri, pr = self.np_rng.random_sample, self.np_rng.randint, self.py_rng
+        cap, n_mem, ratio, gratio = self.capacity, self.n, self.ratio, self.gnoise_ratio
+        mixup, gnoise, rrc, rlf, L = self.mixup, self.gnoise, self.rrc, self.rlf, self.L
+        scale, lscale, in_size = self.scale, self.local_scale, (F, T)
+        per_clip = src_frames is not None and not isinstance(src_frames, (int, np.integer))
+        if per_clip and len(src_frames) != B:
+            raise ValueError(f"src_frames: expected one frame count per clip ({B}), got {len(src_frames)}")
+        starts = [0] * B if src_frames is not None else None
+        ev, loc, mixv = [], [], []
+        events = self.events
+        for b in range(B):
+            if starts is not None:
+                l = int(src_frames[b]) if per_clip else int(src_frames)
+                if l > T:
+                    starts[b] = int(ri(l - T))                         # datasets.py:344
+            for v in range(2):
+                alpha, k, lam, m = 0.0, -1, 0.0, -1
+                if mixup:
+                    alpha = ratio * rs()                               # augmentations.py:105
+                    c = events if events < n_mem else n_mem
+                    if c > 0:
+                        k = int(ri(c))                                 # :108
+                        m = ((events - c + k) // 2) % cap              # global append index of FIFO entry k -> its clip's ring slot
+                    events += 1
+                if gnoise:
+                    lam = gratio * rs()                                # augmentations.py:135 (np.random.rand() is one random_sample)
+                if rrc:
+                    i, j, h, w = draw_rrc_params(canvas, in_size, scale, scale, self.np_rng, pr)
+                else:
+                    i, j, h, w = 0, 0, F, T
+                if rlf:
+                    head = 2.0 * rs() - 1.0                            # augmentations.py:70: 1.0 * (2 * np.random.rand(2) - 1)
+                    tail = 2.0 * rs() - 1.0
+                else:
+                    head = tail = 0.0
+                ev.append((alpha, k, i, j, h, w, head, tail, lam))
+                mixv.append(m)
+            for l_ in range(L):                                        # utils/transforms.py:54-55: the un-mixed clip, no fade
+                loc.append(draw_rrc_params((F, T), in_size, lscale, lscale, self.np_rng, pr))
+        self.events = events
+        self.starts = starts
+        self._last = (self.clips, ev, loc)
+        # event order [clip][view] -> launch order [view][clip]
+        slot = (self.clips + np.arange(B)) % cap
+        a = np.asarray(ev, dtype=np.float64).reshape(B, 2, 9)
+        par = np.empty((2, B, 8), dtype=np.float32)
+        par[:, :, 0] = np.where(a[:, :, 1] >= 0, a[:, :, 0], 0.0).T
+        par[:, :, 1:7] = a[:, :, 2:8].transpose(1, 0, 2)
+        par[:, :, 7] = a[:, :, 8].T
+        src = np.broadcast_to(slot.astype(np.int32), (2, B)).reshape(-1).copy()
+        mix = np.asarray(mixv, dtype=np.int32).reshape(B, 2).T.reshape(-1).copy()
+        self._max_w = float(a[:, :, 5].max())
+        if L:
+            la = np.asarray(loc, dtype=np.float32).reshape(B, L, 4)
+            lpar = np.zeros((L, B, 8), dtype=np.float32)
+            lpar[:, :, 1:5] = la.transpose(1, 0, 2)
+            self.local_draw = (np.broadcast_to(slot.astype(np.int32), (L, B)).reshape(-1).copy(), lpar.reshape(-1, 8))
+            self._max_w_local = float(la[:, :, 3].max())
+        else:
+            self.local_draw = (np.zeros(0, dtype=np.int32), np.zeros((0, 8), dtype=np.float32))
+        return src, mix, par.reshape(-1, 8), canvas
+
+    def __call__(self, B, out=None, drawn=None):
         """Augment the batch previously written into `next_slots(B)`; returns views [2, B, 1, F, T_out] -- or, with local crops, the
-        crop list the reference's transform yields per clip, batched: [view1, view2, local_1 .. local_L], each [B, 1, h, w]."""
+        crop list the reference's transform yields per clip, batched: [view1, view2, local_1 .. local_L], each [B, 1, h, w].
+        `drawn`: what `draw(B, ...)` returned, when the caller sampled ahead of the frontend launch (it needs the crop starts)."""
         self._ensure_store(B)
-        src, mix, par, canvas = self.draw(B)
+        src, mix, par, canvas = drawn if drawn is not None else self.draw(B)
         if out is None:
             out = torch.empty(2, B, 1, self.F, self.T_out, device=self.device)
         noise = None
@@ -308,13 +378,13 @@ class BatchedPairAugment:
             if noise is None:
                 noise = torch.randn(2 * B, self.F, self.T, device=self.device, generator=self.torch_gen)
         _launch(self.store, self.F * self.T, src, mix if self.mixup else None, par, out.view(2 * B, 1, self.F, self.T_out), self.F, self.T,
-                canvas, self.rlf, noise)
+                canvas, self.rlf, noise, max_w=self._max_w)
         crops = out
         if self.L:
             lh, lw = self.local_size
             loc = torch.empty(self.L, B, 1, lh, lw, device=self.device)
             _launch(self.store, self.F * self.T, self.local_draw[0], None, self.local_draw[1], loc.view(self.L * B, 1, lh, lw), self.F, self.T,
-                    (self.F, self.T), False)
+                    (self.F, self.T), False, max_w=self._max_w_local)
             crops = [out[0], out[1]] + [loc[l] for l in range(self.L)]
         self.clips += B
         return crops

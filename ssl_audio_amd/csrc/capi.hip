@@ -16,7 +16,7 @@ extern "C" void sa_set_error(const char* fmt, ...) {
 
 extern "C" const char* sa_last_error(void) { return g_err; }
 
-extern "C" int sa_abi_version(void) { return 5; }
+extern "C" int sa_abi_version(void) { return 6; }
 
 extern "C" int sa_device_info(char* name_host, int name_len, int* cu_count_host) {
   int dev = 0;

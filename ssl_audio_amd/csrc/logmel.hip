@@ -4,7 +4,7 @@
 // and the crop/pad/normalise of datasets.py:342-354 (frontend parity is unpinned by the reference: DESIGN.md §3).
 //
 // A workgroup (4 waves) produces 16 consecutive frames of one clip in two phases, and is persistent: it walks the list of
-// (clip, 16-frame group) pairs with the stride of the grid (3 workgroups per CU), so the tables are fetched once per workgroup.
+// (16-frame group, clip) pairs with the stride of the grid (3 workgroups per CU), so the tables are fetched once per workgroup.
 //   1. One wave per frame, four frames per wave.  The real FFT runs as a 512-point complex FFT of z[n] = x[2n] + i x[2n+1]:
 //      three radix-8 passes (512 = 8*8*8) with the 8 points of each butterfly in one lane's registers as (re, im) pairs -- all
 //      complex arithmetic is packed fp32 (v_pk_add/mul/fma_f32, the rotations by -i folded into op_sel / neg modifiers) -- and two
@@ -88,11 +88,14 @@ __device__ __forceinline__ void lds_st(v2f* p, v2f v) { *(volatile lds_v2f*)(p) 
 // tw: [1024] (cos, -sin) of 2 pi k / 1024, i.e. W_1024^k.  melw: [maxlen][64] weights, mel_lo/mel_len: per band bin range.
 // Persistent: a workgroup takes the 16-frame groups blockIdx.x, blockIdx.x + gridDim.x, ... of the (clip, group) list, so the tables
 // below are fetched once per workgroup, not once per 16 frames.
+template <bool PER_CLIP>
 __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict__ wave, int64_t wave_stride, int L, const float* __restrict__ window,
                                                         const v2f* __restrict__ tw, const float* __restrict__ melw,
                                                         const int* __restrict__ mel_lo, const int* __restrict__ mel_len,
-                                                        float* __restrict__ out, int64_t out_stride, int n_frames, int T_out, int start,
-                                                        float mean, float inv_std, float pad_value, int hop, int groups_per_clip, int n_groups) {
+                                                        float* __restrict__ out, int64_t out_stride, int T_out, int start_all,
+                                                        const int* __restrict__ starts, const int* __restrict__ lengths,
+                                                        const int* __restrict__ offsets, float mean, float inv_std, float pad_value, int hop,
+                                                        int n_clips, int n_groups) {
   __shared__ v2f ex[4][8 * XS];                         // per-wave exchange buffers; the mel partial sums [wave][group][lane] after a group's frames
   __shared__ float pw[FR_PER_BLOCK * PS + 32];          // power spectra [frame][bin], one pad bin per row (+ slack past the last row), zeroed
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -177,35 +180,72 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
     }
   };
 
+  // A group's geometry: its clip and first output frame, and the clip's own numbers (datasets.py:342-351 per sample) -- its first sample inside
+  // the row (offsets), its length in samples (lengths), the source frame its output frame 0 is (starts).  Wave-uniform scalar loads, made
+  // once per group (for the NEXT group at the top of a group's work, so that they have landed when the cross-group prefetch needs them);
+  // NULL arrays = the launch-wide values.  Values that would reach outside the row are clamped; a clip too short to reflect-pad
+  // (<= n_fft / 2 samples) has no frames: its output is all padding.  The list is ordered group-major (all clips' group 0, then all
+  // clips' group 1, ...): the groups that lie in the padding of short clips then sit together at the end of the list instead of
+  // striking some workgroups' walks more than others.
+  struct Geo { int clip, tb, off, L, start, nfr; };
+  auto geometry = [&](int grp, Geo& g) {
+    if (grp >= n_groups) { g.clip = 0; g.tb = 0; g.off = 0; g.L = 0; g.start = 0; g.nfr = 0; return; }
+    const int gi = grp / n_clips;
+    g.clip = grp - gi * n_clips;
+    g.tb = gi * FR_PER_BLOCK;
+    if constexpr (PER_CLIP) {
+      g.off = offsets ? min(max(offsets[g.clip], 0), L) : 0;
+      g.L = lengths ? min(max(lengths[g.clip], 0), L - g.off) : L - g.off;
+      g.start = starts ? max(starts[g.clip], 0) : start_all;
+    } else {
+      g.off = 0; g.L = L; g.start = start_all;
+    }
+    g.nfr = g.L > NFFT / 2 ? 1 + g.L / hop : 0;
+  };
   // samples of one frame: lane n2 holds x[2 (64 n1 + n2)], x[2 (64 n1 + n2) + 1], n1 = 0..7 (reflect padding at the clip's ends).
-  // (grp, f): frame f of this wave in group grp; f == FR_PER_WAVE is the wave's first frame in the workgroup's next group
-  auto fetch = [&](int grp, int f, v2f (&sm)[8]) {
-    if (f == FR_PER_WAVE) { grp += gridDim.x; f = 0; }
-    if (grp >= n_groups) return;
-    const int clip = grp / groups_per_clip, to = (grp - clip * groups_per_clip) * FR_PER_BLOCK + w * FR_PER_WAVE + f;
-    if (to >= T_out || to + start >= n_frames) return;
-    const float* wv = wave + (int64_t)clip * wave_stride;
-    const int base = (to + start) * hop - NFFT / 2;
-    const bool interior = (base >= 0) && (base + NFFT <= L);
+  // (g, f): frame f of this wave in the group g describes
+  auto fetch = [&](const Geo& g, int f, v2f (&sm)[8]) {
+    const int to = g.tb + w * FR_PER_WAVE + f;
+    if (to >= T_out || to + g.start >= g.nfr) return;
+    const float* wv = wave + (int64_t)g.clip * wave_stride + g.off;
+    const int Lc = g.L;
+    const int base = (to + g.start) * hop - NFFT / 2;
+    const bool interior = (base >= 0) && (base + NFFT <= Lc) && !(g.off & 1);   // (8-byte loads need an even first sample)
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
       const int n = 64 * n1 + lane;
       if (interior) sm[n1] = *reinterpret_cast<const v2f*>(wv + base + 2 * n);
-      else sm[n1] = v2f{wv[reflect_idx(base + 2 * n, L)], wv[reflect_idx(base + 2 * n + 1, L)]};
+      else sm[n1] = v2f{wv[reflect_idx(base + 2 * n, Lc)], wv[reflect_idx(base + 2 * n + 1, Lc)]};
     }
   };
   float a[NO * 8];
   load_w(o0, a);
   v2f smp[8] = {};
-  fetch(blockIdx.x, 0, smp);
+  Geo cur, nxt;
+  geometry(blockIdx.x, cur);
+  fetch(cur, 0, smp);
 #if SA_LOGMEL_DBG
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   st[1] = __builtin_readcyclecounter();
 #endif
 
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int clip = grp / groups_per_clip;
-    const int tb = (grp - clip * groups_per_clip) * FR_PER_BLOCK;  // first OUTPUT frame of this group
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x, cur = nxt) {
+    geometry(grp + gridDim.x, nxt);
+    const int clip = cur.clip;
+    const int tb = cur.tb;                       // first OUTPUT frame of this group
+    const int start = cur.start, n_frames = cur.nfr;
+    if (tb + start >= n_frames) {
+      // every frame of the group lies past the clip's end (a clip shorter than the crop): nothing to transform, the rows are the
+      // normalised zero pad.  No LDS traffic, so no barrier; the next group's first frame is requested as after a full group.
+      const int to = tb + i16;
+      if (to < T_out) {
+        float* orow = out + (int64_t)clip * out_stride + (int64_t)(16 * w + 4 * kk) * T_out + to;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) orow[(int64_t)r * T_out] = pad_value;
+      }
+      fetch(nxt, 0, smp);
+      continue;
+    }
 #pragma unroll 1
     for (int f = 0; f < FR_PER_WAVE; ++f) {
       const int to = tb + w * FR_PER_WAVE + f;   // output frame index
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
       v2f v[8];
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) v[n1] = smp[n1] * win[n1];
-      if (f + 1 < FR_PER_WAVE) fetch(grp, f + 1, smp);       // the next frame's samples travel, into the registers just read, while this one is transformed
+      if (f + 1 < FR_PER_WAVE) fetch(cur, f + 1, smp);       // the next frame's samples travel, into the registers just read, while this one is transformed
       if (live) {
         // ---- pass A: DFT8 over n1, twiddle W_512^{n2*k1} = W_1024^{2*n2*k1}
         dft8(v);
@@ -348,7 +388,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
 #if SA_LOGMEL_DBG
     if (grp == blockIdx.x) st[5] = __builtin_readcyclecounter();
 #endif
-    fetch(grp, FR_PER_WAVE, smp);                // the first frame of the workgroup's next group travels behind the two barriers below
+    fetch(nxt, 0, smp);                          // the first frame of the workgroup's next group travels behind the two barriers below
     // group w's four partials, in wave order
     part = reinterpret_cast<f32x4_t*>(&ex[0][0]);
     __syncthreads();
@@ -378,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
   // (diagnostic build, scripts/diag/logmel_stamps.py: the phase durations of the workgroup's first group and its whole life overwrite that group's outputs)
   st[8] = __builtin_readcyclecounter();
   {
-    const int clip = blockIdx.x / groups_per_clip, tb = (blockIdx.x - clip * groups_per_clip) * FR_PER_BLOCK;
+    const int gi0 = blockIdx.x / n_clips, clip = blockIdx.x - gi0 * n_clips, tb = gi0 * FR_PER_BLOCK;
     if (lane == 0 && tb + 8 <= T_out) {
       float* o = out + (int64_t)clip * out_stride + (int64_t)(16 * w) * T_out + tb;
       for (int i = 0; i < 7; ++i) o[i] = (float)(st[i + 1] - st[i]);
@@ -392,12 +432,12 @@ __global__ __launch_bounds__(256, 3) void logmel_kernel(const float* __restrict_
 
 extern "C" int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_clips, int32_t n_samples, const float* window,
                              const float* twiddle, const float* mel_weights, const int32_t* mel_lo, const int32_t* mel_len, float* out,
-                             int64_t out_stride, int32_t T_out, int32_t start, float mean, float stdv, int32_t hop, void* stream) {
+                             int64_t out_stride, int32_t T_out, int32_t start, const int32_t* starts, const int32_t* lengths,
+                             const int32_t* offsets, float mean, float stdv, int32_t hop, void* stream) {
   SA_CHECK_ARG(wave && window && twiddle && mel_weights && mel_lo && mel_len && out, "sa_logmel_fwd: null pointer");
   SA_CHECK_ARG(n_clips > 0 && n_samples > NFFT / 2 && T_out > 0 && hop > 0 && hop % 2 == 0 && start >= 0, "sa_logmel_fwd: bad sizes");
   SA_CHECK_ARG(stdv != 0.f, "sa_logmel_fwd: std must be non-zero");
   SA_CHECK_ARG(((uintptr_t)wave & 7) == 0 && wave_stride % 2 == 0, "sa_logmel_fwd: waveform rows must be 8-byte aligned");
-  const int n_frames = 1 + n_samples / hop;
   const float pad_value = (0.f - mean) / stdv;  // right zero-pad happens BEFORE normalisation (datasets.py:346-354)
   const int groups_per_clip = (T_out + FR_PER_BLOCK - 1) / FR_PER_BLOCK;
   const int64_t n_groups = (int64_t)groups_per_clip * n_clips;
@@ -413,9 +453,10 @@ extern "C" int sa_logmel_fwd(const float* wave, int64_t wave_stride, int32_t n_c
     slots = 3 * prop.multiProcessorCount;
   }
   dim3 grid((unsigned)(n_groups < slots ? n_groups : slots));
-  hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), 0, (hipStream_t)stream, wave, wave_stride, n_samples, window,
-                     reinterpret_cast<const v2f*>(twiddle), mel_weights, mel_lo, mel_len, out, out_stride, n_frames, T_out, start, mean,
-                     1.0f / stdv, pad_value, hop, groups_per_clip, (int)n_groups);
+  auto kernel = (starts || lengths || offsets) ? logmel_kernel<true> : logmel_kernel<false>;
+  hipLaunchKernelGGL(kernel, grid, dim3(256), 0, (hipStream_t)stream, wave, wave_stride, n_samples, window,
+                     reinterpret_cast<const v2f*>(twiddle), mel_weights, mel_lo, mel_len, out, out_stride, T_out, start, starts, lengths,
+                     offsets, mean, 1.0f / stdv, pad_value, hop, n_clips, (int)n_groups);
   SA_LAUNCH_CHECK("sa_logmel_fwd");
   return 0;
 }

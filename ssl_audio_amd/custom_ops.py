@@ -65,7 +65,7 @@ SCHEMAS = {
     "axpy": ("sa_axpy_f32", "(Tensor(a!) y, Tensor x, float a=1.0) -> ()"),
     "count_nonfinite": ("sa_count_nonfinite", "(Tensor x, Tensor(a!) flag) -> ()"),
     "logmel_fwd": ("sa_logmel_fwd", "(Tensor wave, Tensor window, Tensor twiddle, Tensor mel_weights, Tensor mel_lo, Tensor mel_len, Tensor(a!) out, int T_out, "
-                   "int start, float mean, float std, int hop) -> ()"),
+                   "int start, float mean, float std, int hop, Tensor? starts=None, Tensor? lengths=None, Tensor? offsets=None) -> ()"),
     "augment_views": ("sa_augment_views", "(Tensor lms, int clip_stride, Tensor src_slot, Tensor? mix_slot, Tensor params, Tensor(a!) out, int F_in, int T_in, "
                       "int[] canvas, float max_w_ratio, bool do_fade, Tensor? noise=None) -> ()"),
     "normalize_batch": ("sa_normalize_batch", "(Tensor x, Tensor(a!) y, float shift, Tensor(b!) workspace, float eps, float stat_div=1.0) -> ()"),
@@ -112,11 +112,11 @@ SCHEMAS = {
 _LIB = None
 
 
-def _logmel_fwd(wave, window, twiddle, mel_weights, mel_lo, mel_len, out, T_out, start, mean, std, hop):
+def _logmel_fwd(wave, window, twiddle, mel_weights, mel_lo, mel_len, out, T_out, start, mean, std, hop, starts=None, lengths=None, offsets=None):
     """The dispatcher carries tensors, `ops.logmel_fwd` takes frontend.build_tables' dict: the five tables travel as five arguments
     (the registered schema had one `Tensor tables` and could not be called)."""
     ops.logmel_fwd(wave, {"window": window, "twiddle": twiddle, "mel_weights": mel_weights, "mel_lo": mel_lo, "mel_len": mel_len},
-                   out, T_out, start, mean, std, hop)
+                   out, T_out, start, mean, std, hop, starts, lengths, offsets)
 
 
 _ADAPTERS = {"logmel_fwd": _logmel_fwd}       # operators whose dispatcher signature differs from the `ops` function's

@@ -72,16 +72,38 @@ class MelSpectrogram(torch.nn.Module):
     def n_frames(self, n_samples):
         return 1 + n_samples // self.hop
 
-    def forward(self, wave, crop_frames=None, start=0, norm_stats=None, out=None):
-        """norm_stats=(mean, std) applies (x-mean)/std; crop_frames/start follow datasets.py:342-351."""
+    @staticmethod
+    def _per_clip(v, B, device, name):
+        """int / None -> (scalar, None); a sequence or tensor of B ints -> (0, int32 device vector) (staged through pinned memory)."""
+        if v is None or isinstance(v, (int, np.integer)):
+            return int(v or 0), None
+        if isinstance(v, torch.Tensor):
+            t = v.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+        else:
+            h = torch.as_tensor(np.asarray(v, dtype=np.int32))
+            t = (h.pin_memory() if device.type == "cuda" else h).to(device, non_blocking=True)
+        if t.numel() != B:
+            raise ValueError(f"{name}: expected one value per clip ({B}), got {t.numel()}")
+        return 0, t.view(B)
+
+    def forward(self, wave, crop_frames=None, start=0, norm_stats=None, out=None, lengths=None, offsets=None):
+        """norm_stats=(mean, std) applies (x-mean)/std; crop_frames/start follow datasets.py:342-351.
+
+        `start`, `lengths`, `offsets` may each be one value per clip (sequence or tensor): clip b's own crop start in frames
+        (`np.random.randint(l - crop_frames)`, datasets.py:344), its own length in samples (its frames end and reflect there; the rest of
+        the crop is the right zero pad of datasets.py:346-350) and its first sample inside row b (the waveform crop of datasets.py:108-112)
+        -- what `Dataset.__getitem__` does per sample, in one launch."""
         if wave.dim() == 1:
             wave = wave[None]
         if self._tables is None or self._tables["window"].device != wave.device:
             self._tables = build_tables(wave.device, **self.cfg)
         B, L = wave.shape
+        start, starts = self._per_clip(start, B, wave.device, "start")
+        _, lens = self._per_clip(lengths, B, wave.device, "lengths") if lengths is not None else (0, None)
+        _, offs = self._per_clip(offsets, B, wave.device, "offsets") if offsets is not None else (0, None)
         T = crop_frames if crop_frames is not None else self.n_frames(L)
         mean, std = norm_stats if norm_stats is not None else (0.0, 1.0)
         if out is None:
             out = torch.empty(B, 1, self.cfg["n_mels"], T, dtype=torch.float32, device=wave.device)
-        ops.logmel_fwd(wave.contiguous(), self._tables, out.view(B, -1), T, start, mean, std, self.hop)
+        ops.logmel_fwd(wave.contiguous(), self._tables, out.view(B, -1), T, start, mean, std, self.hop, starts, lens, offs)
         return out

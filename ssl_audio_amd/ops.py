@@ -402,13 +402,19 @@ def count_nonfinite(x, flag):
 
 
 # ------------------------------------------------------------------------------------------------ frontend / augmentation
-def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop):
+def logmel_fwd(wave, tables, out, T_out, start, mean, std, hop, starts=None, lengths=None, offsets=None):
+    """starts / lengths / offsets: optional int32 device vectors [B] -- per-clip crop start (frames), clip length (samples) and first
+    sample inside the row (include/ssl_audio_hip.h, ABI v6); None = the scalar `start`, the row length, 0."""
     B, L = wave.shape
+    for name, t in (("starts", starts), ("lengths", lengths), ("offsets", offsets)):
+        if t is not None and (_req(t, torch.int32, name).numel() != B or not t.is_contiguous()):
+            raise ValueError(f"logmel_fwd: {name} must be a contiguous int32 vector of {B} entries")
     # algorithmic bytes (SURVEY.md §8d): the waveform read once + the log-mel written once
     _timed("logmel_kernel", 4.0 * B * L + 4.0 * B * 64 * T_out, lambda: check(
         lib().sa_logmel_fwd(_p(_req(wave, F32, "wave")), wave.stride(0), B, L, _p(tables["window"]), _p(tables["twiddle"]),
                             _p(tables["mel_weights"]), _p(tables["mel_lo"]), _p(tables["mel_len"]), _p(_req(out, F32, "out")),
-                            out.stride(0), T_out, int(start), float(mean), float(std), int(hop), _stream()), "sa_logmel_fwd"),
+                            out.stride(0), T_out, int(start), _p(starts), _p(lengths), _p(offsets), float(mean), float(std), int(hop), _stream()),
+              "sa_logmel_fwd"),
            # per frame: 1024-point FFT (5 N log2 N), window, 513 power bins (3 each), the <= 2 mel bands of every bin (2 x 2 each)
            flops=float(B) * T_out * (5.0 * 1024 * 10 + 1024 + 3 * 513 + 4 * 513))
 

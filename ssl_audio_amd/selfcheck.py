@@ -25,11 +25,15 @@ def synthetic_waveforms(n, n_samples, first_clip=0, device="cpu"):
     return out.to(device)
 
 
-def oracle_step_from_trainer(trainer, waves):
-    """Re-run the trainer's step on the CPU oracle: same waveforms, same parameters, same augmentation draws."""
+def oracle_step_from_trainer(trainer, waves, lengths=None):
+    """Re-run the trainer's step on the CPU oracle: same waveforms, same parameters, same augmentation draws (incl. each clip's dataset
+    crop start, datasets.py:342-345; `lengths`: per-clip sample counts when the rows are padded)."""
     from oracle import augment as oaug, frontend as ofe, step as ostep
     cfg = trainer.cfg
-    lms = ofe.crop_pad_normalize(ofe.logmel(waves.cpu().numpy()), cfg.crop_frames, 0, *AUDIOSET_STATS)   # [B, 64, T]
+    w = waves.cpu().numpy()
+    starts = trainer.augment.starts or [0] * w.shape[0]
+    lms = np.stack([ofe.crop_pad_normalize(ofe.logmel(w[b, :(lengths[b] if lengths is not None else w.shape[1])]), cfg.crop_frames, starts[b],
+                                           *AUDIOSET_STATS) for b in range(w.shape[0])])                  # [B, 64, T]
     B = lms.shape[0]
     views = [np.zeros((B, 1, cfg.n_mels, cfg.crop_frames)), np.zeros((B, 1, cfg.n_mels, cfg.crop_frames))]
     canvas = (cfg.n_mels, int(cfg.crop_frames * cfg.virtual_crop_scale[1]))

@@ -384,18 +384,32 @@ class BarlowTwinsTrainer:
             g["lr"] = value
 
     # ------------------------------------------------------------------ data path
-    def make_views(self, batch):
-        """batch: waveforms [B, L] (from_waveform) or log-mels [B, 1, F, T_any]; -> [view1, view2] each [B,1,F,crop_frames]."""
+    def make_views(self, batch, lengths=None):
+        """batch: waveforms [B, L] (from_waveform) or log-mels [B, 1, F, T_any]; -> [view1, view2] each [B,1,F,crop_frames].
+
+        What `Dataset.__getitem__` does per sample (datasets.py:342-358) happens here per clip, in the reference's RNG order: a clip with
+        more frames than cfg.crop_frames is cropped at its own `np.random.randint(l - crop_frames)`, a shorter one is right-padded, then the
+        clip's views are drawn.  lengths (optional, host sequence of B ints): each clip's length in samples when the rows of `batch` are
+        padded to a common length; default: every clip fills its row."""
         B = batch.shape[0]
         slots = self.augment.next_slots(B)
         if self.from_waveform:
-            self.frontend(batch, crop_frames=self.cfg.crop_frames, start=0, norm_stats=AUDIOSET_STATS, out=slots.view(B, 1, *slots.shape[1:]))
+            if lengths is not None:
+                lengths = [int(n) for n in lengths]
+                src_frames = [self.frontend.n_frames(n) for n in lengths]
+            else:
+                src_frames = self.frontend.n_frames(batch.shape[-1])
+            drawn = self.augment.draw(B, src_frames=src_frames)          # crop starts first: the frontend launch needs them
+            starts = self.augment.starts
+            self.frontend(batch, crop_frames=self.cfg.crop_frames, start=starts if any(starts) else 0, norm_stats=AUDIOSET_STATS,
+                          out=slots.view(B, 1, *slots.shape[1:]), lengths=lengths)
         else:
             slots.copy_(batch.view(B, *batch.shape[-2:]))
+            drawn = None
         out = None
         if self._graph is not None and self.use_graph and self.post_norm is None and self._graph_views[0].shape[0] == B:
             out = self._graph_out()                          # the captured step's input buffers: the augmentation writes them in place
-        views = self.augment(B, out=out)
+        views = self.augment(B, out=out, drawn=drawn)
         crops = [views[i] for i in range(2 + self.L)]        # [view1, view2, local_1 .. local_L] (utils/transforms.py:49-56, batched)
         if self.post_norm is not None:
             crops = [self.post_norm(c) for c in crops]       # main.py:60-65: NormalizeBatch per crop
@@ -406,7 +420,7 @@ class BarlowTwinsTrainer:
         return self._graph_pair
 
     # ------------------------------------------------------------------ one optimisation step
-    def step(self, batch, iteration=None, loader_len=None, mask_ratio=None):
+    def step(self, batch, iteration=None, loader_len=None, mask_ratio=None, lengths=None):
         """One optimisation step on a batch.  With `iteration` (the global training iteration, main.py:48) the per-iteration schedules of
         the reference's loop apply first: the learning rate (utils.adjust_learning_rate when cfg.lr_schedule, main.py:51-57; needs
         loader_len = iterations per epoch) and, in mode 'mae', the mask ratio (mask_ratio_for, main.py:71-81)."""
@@ -414,7 +428,7 @@ class BarlowTwinsTrainer:
             self.apply_schedules(iteration, loader_len)
             if mask_ratio is None and (self.mode == "mae" or getattr(self.cfg, "mask", False)):
                 mask_ratio = self.mask_ratio_for(iteration)
-        return self.step_views(self.make_views(batch), mask_ratio=mask_ratio)
+        return self.step_views(self.make_views(batch, lengths=lengths), mask_ratio=mask_ratio)
 
     def apply_schedules(self, iteration, loader_len):
         """main.py:51-57: `if args.lr_schedule: utils.adjust_learning_rate(args, optimizer, data_loader, iteration)`."""

@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in syms if not hasattr(h, s)]
     assert not missing, missing
     h.sa_abi_version.restype = ctypes.c_int
-    assert h.sa_abi_version() == 5
+    assert h.sa_abi_version() == 6
     # every declared function has ctypes argument types (a missing entry would silently pass ints as 32-bit)
     assert [s for s in syms if s not in _lib._SIGNATURES and s != "sa_last_error"] == []
 
@@ -158,6 +158,39 @@ def test_host_side_pos_embed_and_sampling_match_oracle():
         g = e - min(e, 6) + r["bank_index"]
         slot = mix[r["view"] * 4 + (r["clip"] - 4)]
         assert slot == (g // 2) % 12 and src[r["view"] * 4 + (r["clip"] - 4)] == r["clip"] % 12
+
+
+def test_sampler_draws_dataset_crop_before_the_views_and_matches_numpy_draw_for_draw():
+    """(i) BatchedPairAugment.draw(B, src_frames): each clip's `np.random.randint(l - crop_frames)` (datasets.py:342-345; only when
+    l > crop_frames) comes BEFORE that clip's view draws, as Dataset.__getitem__ crops and then transforms -- starts, crop boxes, mixup
+    draws and fades equal the oracle's sequential `dataset_item`, local crops included.  (ii) The sampler's shortcuts are the numpy / random
+    calls they replace, draw for draw: uniform(a, b) = a + (b - a) * random_sample(), rand(2) = two random_sample(), randint(0, n) =
+    randrange(n + 1)."""
+    import random
+    from oracle import augment as oaug
+    from ssl_audio_amd import augmentations as aug
+    ba = aug.BatchedPairAugment("cpu", 64, 96, 96, seed=3, n_memory=6, local_crops_number=2)
+    ba.capacity = 12
+    orc = oaug.PairTransformOracle(crop_frames=96, seed=3, n_memory=6, local_crops_number=2)
+    for it in range(6):
+        fr = [1001, 50, 96, 300 + it]
+        ba.draw(4, src_frames=fr)
+        ba.clips += 4
+        st = [orc.dataset_item(np.zeros((1, 64, l)))[1] for l in fr]
+        assert st == ba.starts and st[1] == st[2] == 0 and 0 <= st[0] < 1001 - 96
+        recs = orc.records[-16:]
+        assert [tuple(r["rrc"]) for r in ba.records] == [tuple(r["rrc"]) for r in recs]
+        glob = [r for r in recs if "alpha" in r]
+        mine = [r for r in ba.records if "alpha" in r]
+        assert [r["alpha"] for r in mine] == [r["alpha"] for r in glob] and [r["bank_index"] for r in mine] == [r["bank_index"] for r in glob]
+        assert [r["head_tail"] for r in mine] == [tuple(r["head_tail"]) for r in glob]
+    assert ba.draw(4) and ba.starts is None                       # without src_frames no crop draw is made (the pre-cropped path)
+    a, b = np.random.RandomState(7), np.random.RandomState(7)
+    for lo, hi in ((0.6, 1.5), (0.05, 0.6)):
+        assert all(a.uniform(lo, hi) == lo + (hi - lo) * b.random_sample() for _ in range(50000))
+    assert all(tuple(a.rand(2)) == (b.random_sample(), b.random_sample()) for _ in range(1000))
+    p, q = random.Random(5), random.Random(5)
+    assert all(p.randint(0, n) == q.randrange(n + 1) for n in list(range(1, 700)) * 5)
 
 
 def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():

@@ -377,6 +377,73 @@ def test_logmel(dev, L, T, start):
     assert d.max() < 2e-3, d.max()
 
 
+def test_logmel_per_clip_start_length_offset(dev):
+    """ABI v6: ONE launch does what Dataset.__getitem__ does per sample (datasets.py:342-351): every clip its own crop start
+    (`np.random.randint(l - crop_frames)`), its own length (frames end -- and the reflect padding mirrors -- at ITS last sample; shorter
+    than the crop: right zero pad before the normalisation) and, for the waveform-level crop of datasets.py:108-112, its own first
+    sample inside the row (odd offsets take the element-wise load path).  Against the oracle run clip by clip on the cropped waveform."""
+    from oracle import frontend as ofe
+    T, hop = 96, 160
+    lens = [160000, 15200, 48000, 9000, 600, 160000, 31999, 16000, 511, 20000]     # 511 samples: too short to reflect-pad -> all pad
+    offs = [0, 2, 1001, 0, 64, 0, 7, 3, 0, 139999]
+    n = len(lens)
+    wave = synth_wave(n, 160000, 43)
+    rng = np.random.RandomState(3)
+    starts = []
+    for L_, o in zip(lens, offs):
+        assert o + L_ <= 160000
+        l = 1 + L_ // hop
+        starts.append(int(rng.randint(l - T)) if l > T else 0)
+    starts[5] = (1 + 160000 // hop) - T                      # a crop that ends on the clip's last frame
+    starts[2] = (1 + 48000 // hop) - 40                      # a "start" past l - crop: 40 live frames, then pad (the kernel must not read on)
+    mel = fe.MelSpectrogram()
+    out = mel(wave.to(dev), crop_frames=T, start=starts, lengths=lens, offsets=offs, norm_stats=(-0.8294, 4.6230)).cpu().numpy()[:, 0]
+    pad = (0.0 + 0.8294) / 4.6230
+    for b in range(n):
+        if lens[b] <= 512:
+            assert np.all(out[b] == np.float32(pad)), b
+            continue
+        lms = ofe.logmel(wave[b, offs[b]:offs[b] + lens[b]].numpy())
+        ref = (np.pad(lms[:, starts[b]:starts[b] + T], [(0, 0), (0, max(0, T - (lms.shape[-1] - starts[b])))]) + 0.8294) / 4.6230
+        d = np.abs(out[b] - ref)
+        assert d.max() < 2e-3, (b, d.max())
+    # the arrays are optional one by one, and device tensors are accepted as they are
+    o2 = mel(wave.to(dev), crop_frames=T, start=torch.tensor(starts, dtype=torch.int32, device=dev), norm_stats=(-0.8294, 4.6230))
+    o3 = mel(wave[:1].to(dev), crop_frames=T, start=starts[0], norm_stats=(-0.8294, 4.6230))
+    assert torch.equal(o2[0], o3[0])
+    with pytest.raises(ValueError):
+        mel(wave.to(dev), crop_frames=T, start=starts[:3])
+
+
+def test_logmel_padding_groups_do_no_transform_work(dev):
+    """Clips shorter than the crop: the 16-frame groups that lie wholly in the padding are written without FFT / MFMA work, so a batch
+    of 1 s clips padded to 1001 frames costs about a tenth of a batch of 10 s clips (and equals the oracle's right zero pad)."""
+    from oracle import frontend as ofe
+    B, T = 128, 1001
+    wave = synth_wave(B, 160000, 47).to(dev)
+    mel = fe.MelSpectrogram()
+    lens = torch.full((B,), 16000, dtype=torch.int32, device=dev)       # (a device vector: no host staging inside the timed calls)
+    full = mel(wave, crop_frames=T, norm_stats=(-0.8294, 4.6230))
+    short = mel(wave, crop_frames=T, lengths=lens, norm_stats=(-0.8294, 4.6230))
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+    t_full = timed(lambda: mel(wave, crop_frames=T, norm_stats=(-0.8294, 4.6230), out=full))
+    t_short = timed(lambda: mel(wave, crop_frames=T, lengths=lens, norm_stats=(-0.8294, 4.6230), out=short))
+    ref = ofe.crop_pad_normalize(ofe.logmel(wave[:2, :16000].cpu().numpy()), T, 0, -0.8294, 4.6230)
+    assert np.abs(short[:2, 0].cpu().numpy() - ref).max() < 2e-3
+    assert torch.all(short[:, :, :, 101:] == short[0, 0, 0, 1000])
+    print(f"logmel 128 clips: 10 s {t_full * 1e3:.1f} us, 1 s padded to 1001 frames {t_short * 1e3:.1f} us")
+    assert t_short < 0.5 * t_full, (t_short, t_full)
+
+
 def test_logmel_many_groups(dev):
     """More 16-frame groups than the persistent kernel has workgroups (3 per CU): every workgroup walks several (clip, group) pairs,
     the last group of a clip is ragged (101 frames = 6 x 16 + 5) and the first frame of the next pair is prefetched across the boundary."""

@@ -476,6 +476,60 @@ def test_batched_augment_matches_sequential_oracle(dev):
     assert [r["rrc"] for r in ba.records] == [tuple(r["rrc"]) for r in orc.records[-2 * B:]]
 
 
+def test_batched_augment_with_dataset_crop_matches_sequential_oracle(dev):
+    """The reference's DEFAULT data path (crop_frames = 96, utils/hyperparameters.py:49-50, from 10 s clips): Dataset.__getitem__ crops
+    every sample at its own `np.random.randint(l - crop_frames)` -- or right-pads a short one -- and only then runs the pair transform
+    (datasets.py:342-358), all on the global numpy stream.  BatchedPairAugment.draw(B, src_frames) draws the start of a clip before
+    that clip's view draws; the cropped log-mels go into the ring; views, starts and RNG order equal the oracle's sequential
+    `dataset_item` over 3 batches (bank spans batches)."""
+    from oracle import augment as oaug
+    B, T_ = 4, 96
+    frames = [1001, 1001, 60, 96, 500, 1001, 97, 1001, 1001, 30, 1001, 1001]
+    rng = np.random.RandomState(9)
+    ba = aug.BatchedPairAugment(dev, 64, T_, T_, seed=17, n_memory=10)
+    orc = oaug.PairTransformOracle(crop_frames=T_, seed=17, n_memory=10)
+    for it in range(3):
+        fr = frames[B * it:B * (it + 1)]
+        clips = [(rng.randn(1, 64, l) * 1.3 - 0.2).astype(np.float32) for l in fr]
+        drawn = ba.draw(B, src_frames=fr)
+        slots = ba.next_slots(B)
+        for b in range(B):                                   # what the frontend launch does with `starts` / `lengths`: crop or right-pad
+            s0 = ba.starts[b]
+            x = np.zeros((64, T_), dtype=np.float32)
+            x[:, :min(T_, fr[b] - s0)] = clips[b][0, :, s0:s0 + T_]
+            slots[b].copy_(T(x, dev))
+        views = ba(B, drawn=drawn).cpu().numpy()
+        for b in range(B):
+            ref, s0 = orc.dataset_item(clips[b])
+            assert s0 == ba.starts[b] and (s0 > 0 or fr[b] <= T_ + 1)
+            for v in range(2):
+                assert np.abs(views[v, b] - ref[v]).max() < 2e-4, (it, b, v)
+        assert [r["rrc"] for r in ba.records] == [tuple(r["rrc"]) for r in orc.records[-2 * B:]]
+        assert [r["bank_index"] for r in ba.records] == [r["bank_index"] for r in orc.records[-2 * B:]]
+
+
+def test_trainer_default_crop_from_long_clips_vs_oracle(dev):
+    """Whole data path of a step at the reference's default crop (96 frames) from longer, ragged clips: waveforms [B, L] + per-clip lengths
+    -> ONE frontend launch with per-clip starts / lengths (sa_logmel_fwd, ABI v6) -> views -> step; against the oracle's per-sample
+    pipeline (log-mel of each clip's own samples, dataset crop / pad, pair transform) and its fp32 step."""
+    from ssl_audio_amd import selfcheck
+    from ssl_audio_amd.train import BarlowTwinsTrainer
+    B, L = 8, 48000
+    cfg = hp.make_args(model_type="vit_tiny", batch_size=B, crop_frames=96, projector_hidden_dim=512, projector_out_dim=128)
+    trainer = BarlowTwinsTrainer(cfg, dev, mode="bt", batch_per_rank=B, clip_samples=L, seed=0)
+    trainer._initial_state = {k: v.detach().clone() for k, v in trainer.online.state_dict().items()}
+    waves = selfcheck.synthetic_waveforms(B, L, device=dev)
+    lengths = [48000, 48000, 8000, 15200, 30000, 48000, 15360, 47999]
+    loss = float(trainer.step(waves, lengths=lengths))
+    starts = trainer.augment.starts
+    for s0, n in zip(starts, lengths):
+        l = 1 + n // 160
+        assert (0 <= s0 < l - 96) if l > 96 else s0 == 0
+    assert sum(s0 > 0 for s0 in starts) >= 4
+    ref_loss, _, _, _ = selfcheck.oracle_step_from_trainer(trainer, waves, lengths=lengths)
+    assert np.isfinite(loss) and abs(loss - ref_loss) / abs(ref_loss) < 3e-2, (loss, ref_loss)
+
+
 def test_batched_augment_local_crops_and_gnoise_match_sequential_oracle(dev):
     """the batched device path with L = 2 local crops (utils/transforms.py:38-47,54-55) and --Gnoise
     (utils/transforms.py:21-22) == the oracle's sequential per-clip pipeline: same RNG call order (two globals -- each mixup, noise
