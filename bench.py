@@ -129,12 +129,33 @@ def cpu_baseline(workload, budget_clips=8, steps=16):
                       f"{torch.get_num_threads()} threads of {avail} visible cores (oracle/: frontend + augment + fwd/bwd + AdamW)"}
 
 
+def profiler_in_environment():
+    """The marker of a rocprofiler tool library injected into this process (rocprofv3 sets these for the program it starts), or None."""
+    for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH", "ROCPROF_OUTPUT_FILE_NAME"):
+        if os.environ.get(k):
+            return f"{k} is set"
+    for k in os.environ:
+        if k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_"):
+            return f"{k} is set"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return "LD_PRELOAD holds a rocprofiler library"
+    return None
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD process (never a re-exec; nothing
-    in this parent has touched the GPU: no torch.cuda call, no ops.lib()), the way the reference is launched -- one process per GPU
-    from torchrun's environment (utils/utils.py:335-361).  The child's stdout (rank 0's single JSON line) and stderr pass through."""
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a CHILD process (never a re-exec), the
+    way the reference is launched -- one process per GPU from torchrun's environment (utils/utils.py:335-361).  Nothing in THIS code has
+    touched the GPU at that point (no torch.cuda call, no ops.lib()); a profiler that injected itself into the process has, which is
+    why a profiled parent refuses (profiler_in_environment).  The child's stdout (rank 0's single JSON line) and stderr pass through."""
     import socket
     import subprocess
+    prof = profiler_in_environment()
+    if prof and not args.dry_launch:
+        # Under rocprofv3 the profiler's preloaded library has ALREADY initialised the GPU in this process (always so with --pmc), so
+        # starting the ranks from here is the fork + exec out of a GPU-initialised process that takes this pool's machines down.
+        print(f"[bench] refusing to self-launch {args.gpus} ranks from a profiled process ({prof}): profile one rank per profiler "
+              "(`torch.distributed.run ... rocprofv3 ... -- python3 bench.py` is NOT that either) or profile `--gpus 1`", file=sys.stderr, flush=True)
+        return 3
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -151,6 +172,37 @@ def self_launch(args):
     env["SA_BENCH_PARENT"] = str(os.getpid())
     print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_name():
+    if os.environ.get("TORCHELASTIC_RUN_ID") is not None and os.environ.get("SA_BENCH_PARENT"):
+        return "torch.distributed.run (self-launched child)"
+    return "torch.distributed.run" if "RANK" in os.environ else "single process"
+
+
+def dry_run(args):
+    """The launch path of a real run without its GPU work: process group from the launcher's environment (dist.init_from_env, the same
+    call), world-size check, one MAX all-reduce like the one that closes the timed region, rank 0 prints the launch fields.  No value."""
+    from ssl_audio_amd import dist as sdist
+    hsa_before = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")         # (dist's import has already set it when it was unset)
+    rank, local, world = sdist.init_from_env(None if os.environ.get("SA_DIST_BACKEND") else "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "clips/sec (10 s, 64-mel, ViT-B, BT loss) at 1/2/4/8 MI355X + CPU ref", "value": None, "dry_run": True,
+                          "n_gpus": world, "config": {"workload": args.workload, "parallelism": f"dp{world}", "dist_world": sdist.get_world_size(),
+                                                      "dist_backend": torch.distributed.get_backend() if sdist.is_dist_avail_and_initialized() else None,
+                                                      "launcher": launcher_name(), "max_rank_plus_1": float(t),
+                                                      "grad_dtype": args.grad_dtype or os.environ.get("SA_GRAD_DTYPE", "fp32"),
+                                                      "env": {"HSA_ENABLE_IPC_MODE_LEGACY": hsa_before, "LOCAL_RANK": os.environ.get("LOCAL_RANK"),
+                                                              "MASTER_ADDR": os.environ.get("MASTER_ADDR")}}}), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0
 
 
 def main():
@@ -174,9 +226,16 @@ def main():
                     "which already keep the GPU saturated (42.7 vs 43.3 ms per step)")
     ap.add_argument("--no_graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--profile_steps", type=int, default=3, help="eager steps with per-launch HIP events after the timed region (roofline)")
+    ap.add_argument("--grad_dtype", default=None, choices=["fp32", "bf16"], help="what the gradient all-reduce carries (train.GradSync): fp32 "
+                    "(default) or bf16 staging buckets at half the bytes, accumulated back into the fp32 gradients")
+    ap.add_argument("--dry_run", action="store_true", help="rendezvous only: initialise the process group exactly as a real run does, "
+                    "exchange one tensor, print the launch / environment fields of the JSON line with value null -- no GPU is touched "
+                    "(CPU rehearsal of the N > 1 launch: SA_DIST_BACKEND=gloo)")
     args = ap.parse_args()
     if "RANK" not in os.environ and (args.gpus > 1 or args.dry_launch or os.environ.get("SA_BENCH_SELF_LAUNCH") == "1"):
         sys.exit(self_launch(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to fd 1 when its first communicator comes up, so
     # the process-level stdout is parked on stderr until the result is ready
@@ -215,7 +274,7 @@ def main():
     frames = (n_samples // 160 + 1) // 16 * 16 if mode == "mae" else n_samples // 160 + 1      # MAE: whole patches (992)
     cfg = hp.make_args(model_type=model_type, batch_size=B * world, crop_frames=frames, dataset="audioset",
                        stop_gradient=(mode == "byol"), predictor=(mode == "byol"), **extra)
-    trainer = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=B, clip_samples=n_samples, seed=0)
+    trainer = BarlowTwinsTrainer(cfg, dev, mode=mode, batch_per_rank=B, clip_samples=n_samples, seed=0, grad_dtype=args.grad_dtype)
 
     # synthetic waveforms resident in HBM: 2 alternating batches, distinct per rank (cheap device-side recipe of the
     # same family as BASELINE.md §3: noise + 3 sinusoids)
@@ -301,13 +360,18 @@ def main():
         gemm_flop = sum(fl for _, _, fl, *_ in prof)
         n_launch = max(len(prof), 1)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        by_kind, by_kernel = {}, {}
-        for e0, e1, fl, kind, nb, kname in prof:
+        by_kind, by_kernel, by_symbol = {}, {}, {}
+        for e0, e1, fl, kind, nb, kname, symbol in prof:
             t = e0.elapsed_time(e1)
             ms, f = by_kind.get(kind, (0.0, 0.0))
             by_kind[kind] = (ms + t, f + fl)
-            k = by_kernel.setdefault(kname, [0.0, 0.0, 0.0, 0])
-            k[0] += t; k[1] += fl; k[2] += nb; k[3] += 1
+            for table, key in ((by_kernel, kname), (by_symbol, symbol)):
+                k = table.setdefault(key, [0.0, 0.0, 0.0, 0])
+                k[0] += t; k[1] += fl; k[2] += nb; k[3] += 1
+        # `dom` below groups launches by kernel FUNCTION (all template instances of one __global__); rocprofv3 lists every instance as its own
+        # symbol, and by that grouping another kernel may lead (the split-K weight gradient): name it beside the family
+        top_sym = max(by_symbol, key=lambda k: by_symbol[k][0])
+        s_ms, s_fl, s_nb, s_n = by_symbol[top_sym]
         # the DOMINANT device kernel (most time in the timed region) carries the roofline object; names match rocprofv3's
         dom = max(by_kernel, key=lambda k: by_kernel[k][0])
         d_ms, d_fl, d_nb, d_n = by_kernel[dom]
@@ -352,8 +416,8 @@ def main():
                        "profiled_ms_per_step": round(dtp / psteps * 1e3, 3), "parallelism": f"dp{world}", "gflop_per_clip": GF_PER_CLIP[args.workload],
                        "loss": round(loss_val, 4),
                        "dist_world": sdist.get_world_size(), "dist_backend": dist_backend, "rccl_version": rccl_version,
-                       "launcher": "torch.distributed.run (self-launched child)" if os.environ.get("TORCHELASTIC_RUN_ID") is not None
-                       and os.environ.get("SA_BENCH_PARENT") else ("torch.distributed.run" if "RANK" in os.environ else "single process")},
+                       "launcher": launcher_name(), "grad_dtype": trainer.sync.grad_dtype,
+                       "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}},
             # which bound applies: the kernel's arithmetic intensity against the ridge (2 500 TFLOP/s / 8 TB/s = 312 flop/B).  ViT-B's GEMMs sit
             # above it (MFMA-bound); ViT-T's (d = 192: three K-tiles per output tile, weight gradients that read 245 MB for 38 GFLOP)
             # far below, so their roofline is HBM and `frac` is the fraction of 8 TB/s the algorithmic bytes move at
@@ -361,7 +425,11 @@ def main():
                           "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4)} if d_fl / max(d_nb, 1.0) >= PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS else
                          {"bound": "hbm", "achieved": round(d_nb / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(d_nb / (d_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}) | {
-                         "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16)",
+                         "kernel": dom + " (bf16 MFMA 16x16x32, sa_gemm_bf16; all template instances of the function)",
+                         "largest_single_symbol": {"kernel": top_sym, "launches": s_n, "avg_launch_us": round(s_ms * 1e3 / s_n, 2),
+                                                   "tflops": round(s_fl / (s_ms * 1e-3) / 1e12, 1), "frac": round(s_fl / (s_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                   "hbm_gbs_algorithmic": round(s_nb / (s_ms * 1e-3) / 1e9, 1),
+                                                   "share_of_step": round((s_ms / psteps) / (dt / args.steps * 1e3), 4)},
                          "intensity_flop_per_byte": round(d_fl / max(d_nb, 1.0), 1), "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS, 1),
                          "mfma": {"achieved": round(d_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(d_tflops / PEAK_BF16_TFLOPS, 4)},
                          "hbm": {"achieved": round(d_nb / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

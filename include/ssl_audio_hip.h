@@ -84,6 +84,10 @@ int sa_set_dynamic_tiles(int32_t on);
 
 /* fp32 -> bf16 cast of a flat buffer (weights once per step, activations where needed) */
 int sa_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* bf16 -> fp32 of a flat buffer (ABI v6): the way back from the bf16 gradient buckets of the data-parallel exchange -- a gradient range is cast
+ * to bf16, SUM all-reduced over the ranks at half the bytes, and widened back into the fp32 gradient buffer (train.GradSync, grad_dtype
+ * "bf16"; the reference's DDP all-reduces fp32 or, under autocast, fp16 gradient buckets: utils/utils.py:410-417). */
+int sa_cast_bf16_to_f32(const void* src_bf16, float* dst, int64_t n, void* stream);
 /* dst[c][r] = src[r][c], bf16 [R][C] -> [C][R] (R, C multiples of 8).  The engine keeps a transposed bf16 copy of every Linear weight so that
  * the data gradients dX = dY W run in the forward (k-contiguous x k-contiguous) operand layout, measured 6-16 % faster than reading W
  * k-strided; refreshed once per optimiser step. */
@@ -157,10 +161,14 @@ int sa_bn_bwd_apply(const void* dy, int32_t dy_is_bf16, int64_t lddy, const floa
 /* ------------------------------------------------------------------ Barlow Twins loss pieces (fp32, exact-fp32 MFMA)
  * Replaces utils/loss.py:15-30.  sa_matmul_f32: C[m][n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
  * (c = z1n^T z2n / B, dz1n = z2n G^T / B, dz2n = z1n G / B).  sa_bt_loss_grad: loss (1 float, overwritten) and
- * G = dL/dc from the (already all-reduced) cross-correlation matrix c [D][D]; G may be NULL. */
+ * G = dL/dc from the (already all-reduced) cross-correlation matrix c [D][D]; G may be NULL.  ws: sa_bt_loss_workspace_bytes() of
+ * scratch for the per-block partial sums, added in block order by a second launch (no float atomics).  ABI v6: the scratch is the
+ * CALLER's (until v5 a device global of the library, shared by every stream and thread of a process): callers that launch from several
+ * streams or threads hand in one buffer per stream. */
 int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
                   int32_t M, int32_t N, int32_t K, float alpha, void* stream);
-int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream);
+int64_t sa_bt_loss_workspace_bytes(void);
+int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, float* ws, void* stream);
 /* The loss term fused around its three collectives (ABI v5; SURVEY.md section 2.3 "K7", utils/loss.py:15-30): five launches instead of
  * the fifteen of the piecewise schedule above, same arithmetic.
  *   sa_bt_stats2        stats [2][2][D] = per view (mean, M2) of the local rows of z1, z2 [B][D] (row stride ld)       -> all-gather
@@ -277,19 +285,23 @@ int sa_token_group_sum(const float* y, int32_t S, int32_t N, int32_t d, int32_t 
 
 /* MAE decoder input (forward_decoder, models/mae.py:413-420): mask tokens appended, un-shuffled by ids_restore, decoder
  * positional table added.  x [B][1+keep][d], out [B][1+L][d]; bwd WRITES dx (kept rows are a permutation) and ADDS the
- * masked rows into dmask_token. */
+ * masked rows into dmask_token (d <= 2048) through ws: sa_mae_unshuffle_bwd_workspace_bytes() of caller-owned, 16-byte aligned scratch for
+ * the row groups' partial sums, added in group order (ABI v6; required when dmask_token is given; one buffer per stream). */
+int64_t sa_mae_unshuffle_bwd_workspace_bytes(void);
 int sa_mae_unshuffle_fwd(const float* x, int32_t keep, const float* mask_token, const float* pos, const int32_t* ids_restore, int32_t B,
                          int32_t L, int32_t d, float* out, void* stream);
 int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32_t* ids_restore, int32_t B, int32_t L, int32_t d, float* dx,
-                         float* dmask_token, void* stream);
+                         float* dmask_token, float* ws, void* stream);
 
 /* MAE reconstruction loss (forward_loss + patchify, models/mae.py:437-453, :282-293; one input channel):
  * loss = sum_l mask * mean_p (pred - target)^2 / sum mask, target = patchify(img), with norm_pix != 0 normalised per patch
  * ((t - mean) / sqrt(var + 1e-6), unbiased variance: models/mae.py:443-446; ABI v5).  acc2 = {numerator, sum mask} (kept for the backward);
  * bwd: dpred = gscale[0] * 2 * mask * (pred - target) / (P * sum mask).  pred / dpred are [B][pred_row0 + L][P] with
- * pred_seq_stride elements per clip: pred_row0 = 1 reads decoder_pred's output in place (its CLS row gets gradient 0). */
+ * pred_seq_stride elements per clip: pred_row0 = 1 reads decoder_pred's output in place (its CLS row gets gradient 0).
+ * ws (ABI v6): sa_mae_recon_loss_workspace_bytes() of caller-owned scratch for the per-block partial sums (one buffer per stream). */
+int64_t sa_mae_recon_loss_workspace_bytes(void);
 int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
-                          int32_t norm_pix, float* acc2, float* loss, void* stream);
+                          int32_t norm_pix, float* acc2, float* loss, float* ws, void* stream);
 int sa_mae_recon_loss_bwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, const float* acc2, const float* gscale, int32_t B,
                           int32_t F, int32_t T, int32_t ph, int32_t pw, int32_t norm_pix, float* dpred, void* stream);
 /* loss[0] = acc2[0] / acc2[1] again, after acc2 was summed over data-parallel ranks (global masked mean: what one process computes

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "sa_device_info": [C.c_char_p, I32, C.POINTER(I32)],
     "sa_gemm_bf16": [C.POINTER(SaGemmArgs), P],
     "sa_cast_f32_to_bf16": [P, P, I64, P],
+    "sa_cast_bf16_to_f32": [P, P, I64, P],
     "sa_transpose_bf16": [P, I32, I32, P, P],
     "sa_transpose_bf16_batch": [P, I32, I32, P],
     "sa_colsum_bf16": [P, I64, I32, I32, P, I32, P, I32, I64, P],
@@ -56,8 +57,11 @@ _SIGNATURES = {
     "sa_mean_tokens_fwd": [P, I32, I32, I32, P, P],
     "sa_mean_tokens_bwd": [P, I32, I32, I32, P, P],
     "sa_mae_unshuffle_fwd": [P, I32, P, P, P, I32, I32, I32, P, P],
-    "sa_mae_unshuffle_bwd": [P, I32, P, I32, I32, I32, P, P, P],
-    "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, I32, P, P, P],
+    "sa_mae_unshuffle_bwd": [P, I32, P, I32, I32, I32, P, P, P, P],
+    "sa_mae_recon_loss_fwd": [P, I64, I32, P, P, I32, I32, I32, I32, I32, I32, P, P, P, P],
+    "sa_mae_unshuffle_bwd_workspace_bytes": [],
+    "sa_mae_recon_loss_workspace_bytes": [],
+    "sa_bt_loss_workspace_bytes": [],
     "sa_mae_recon_loss_bwd": [P, I64, I32, P, P, P, P, I32, I32, I32, I32, I32, I32, P, P],
     "sa_mae_recon_loss_finalize": [P, P, P],
     "sa_maxpool3s2_fwd": [P, I32, I32, I32, I32, P, P, P, P],
@@ -93,7 +97,7 @@ _SIGNATURES = {
     "sa_bn_bwd_apply": [P, I32, I64, P, I64, I32, I32, P, P, P, P, I32, P, P, F32, P, P, P, I64, P],
     "sa_bn_finalize": [P, I64, I32, I32, I32, F32, F32, P, P, P, P, P],
     "sa_matmul_f32": [P, I64, I64, P, I64, I64, P, I64, I32, I32, I32, F32, P],
-    "sa_bt_loss_grad": [P, I32, F32, F32, I32, P, P, P],
+    "sa_bt_loss_grad": [P, I32, F32, F32, I32, P, P, P, P],
     "sa_bt_stats2": [P, P, I64, I32, I32, P, P],
     "sa_bt_corr": [P, P, I64, I32, I32, P, I32, F32, F32, F32, P, P, P, P, P, P, P, P],
     "sa_bt_bwd_products": [P, P, I32, I32, P, F32, P, P, P],

@@ -185,12 +185,12 @@ __global__ __launch_bounds__(64) void matmul_f32_kernel(const float* __restrict_
 
 // ---- loss = alpha * sum_i (c_ii - 1)^2 + lambda * sum_{i != j} (c_ij [+1])^2 ; G = dL/dc   (utils/loss.py:23-30)
 // The loss scalar is summed in a fixed order (no float atomics: bit-reproducible): every block leaves its partial in bt_loss_partials and a
-// one-wave launch adds them in block order.  The partials are a device global of this library: launches that share it are ordered on
-// one stream (the loss terms of a step are), like every workspace the host side hands in.
-__device__ float bt_loss_partials[256];
+// one-wave launch adds them in block order.  The partials live in the caller's workspace (256 floats): launches on different streams or
+// threads bring their own (a device global here was silently shared by all of them).
+constexpr int BT_LOSS_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restrict__ c, int D, float alpha, float lambda, int hsic,
-                                                           float* __restrict__ G) {
+                                                           float* __restrict__ G, float* __restrict__ bt_loss_partials) {
   __shared__ float red[4];
   float s = 0.f;
   const int n = D * D;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void bt_loss_grad_kernel(const float* __restri
   if (threadIdx.x == 0) bt_loss_partials[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(64) void bt_loss_finish_kernel(int nblocks, float* __restrict__ loss) {
+__global__ __launch_bounds__(64) void bt_loss_finish_kernel(int nblocks, float* __restrict__ loss, const float* __restrict__ bt_loss_partials) {
   // lane l adds the partials l, l + 64, ... in order; the 64 lane sums are then added in lane order by lane 0
   __shared__ float lanes[64];
   float a = 0.f;
@@ -395,11 +395,14 @@ extern "C" int sa_matmul_f32(const float* A, int64_t sam, int64_t sak, const flo
   return 0;
 }
 
-extern "C" int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, void* stream) {
+extern "C" int64_t sa_bt_loss_workspace_bytes(void) { return (int64_t)BT_LOSS_BLOCKS * sizeof(float); }
+
+extern "C" int sa_bt_loss_grad(const float* c, int32_t D, float alpha, float lambda, int32_t hsic, float* loss, float* G, float* ws, void* stream) {
   SA_CHECK_ARG(c && loss && D > 0, "sa_bt_loss_grad: bad args");
-  int grid = (int)(((int64_t)D * D + 255) / 256 < 256 ? ((int64_t)D * D + 255) / 256 : 256);
-  hipLaunchKernelGGL(bt_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c, D, alpha, lambda, hsic, G);
-  hipLaunchKernelGGL(bt_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, loss);
+  SA_CHECK_ARG(ws, "sa_bt_loss_grad: needs a workspace (sa_bt_loss_workspace_bytes)");
+  int grid = (int)(((int64_t)D * D + 255) / 256 < BT_LOSS_BLOCKS ? ((int64_t)D * D + 255) / 256 : BT_LOSS_BLOCKS);
+  hipLaunchKernelGGL(bt_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, c, D, alpha, lambda, hsic, G, ws);
+  hipLaunchKernelGGL(bt_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, loss, ws);
   SA_LAUNCH_CHECK("sa_bt_loss_grad");
   return 0;
 }
@@ -433,6 +436,33 @@ extern "C" int sa_adamw_step_dev(float* p, const float* g, float* m, float* v, i
   SA_CHECK_ARG(p && g && m && v && n >= 0 && hyper3, "sa_adamw_step_dev: bad args (hyper3 = device {lr, 1/(1-b1^t), 1/sqrt(1-b2^t)})");
   if (n == 0) return 0;
   return adamw_launch(p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale, p_bf16, hyper3, skip_flag, stream);
+}
+
+namespace {
+// bf16 -> fp32 over a flat buffer: the way back from the bf16 gradient buckets of the data-parallel exchange (train.GradSync, grad_dtype bf16)
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i);
+      *reinterpret_cast<float4*>(dst + i) = make_float4(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]));
+      *reinterpret_cast<float4*>(dst + i + 4) = make_float4(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]));
+    } else {
+      for (int64_t k = i; k < n; ++k) dst[k] = bf2f(src[k]);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int sa_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  SA_CHECK_ARG(n >= 0 && (n == 0 || (src && dst)), "sa_cast_bf16_to_f32: bad args");
+  if (n == 0) return 0;
+  SA_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "sa_cast_bf16_to_f32: pointers must be 16-byte aligned");
+  const int64_t want = (n + 8 * 256 - 1) / (8 * 256);
+  const int grid = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+  SA_LAUNCH_CHECK("sa_cast_bf16_to_f32");
+  return 0;
 }
 
 extern "C" int sa_ema_update(float* target, const float* online, int64_t n, float beta, void* stream) {

@@ -124,13 +124,13 @@ __global__ void mae_unshuffle_kernel(const float* __restrict__ x, int keep, cons
   }
 }
 
-constexpr int UNSH_MAXD = 2048, UNSH_GROUPS = 128;
-__device__ float unshuffle_partials[UNSH_GROUPS * UNSH_MAXD];     // per row group: the mask-token gradient partial (one launch at a time per stream)
+constexpr int UNSH_MAXD = 2048, UNSH_GROUPS = 128;      // the caller's workspace: per row group the mask-token gradient partial, [UNSH_GROUPS][UNSH_MAXD] floats
 
 // adjoint: dx rows are a permutation of the kept rows of dout (written, not accumulated); dmask_token += sum over masked rows.
 // One block column per 64 float4 columns, blockIdx.y strides over (b, row); the mask-token partial stays in registers.
 __global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __restrict__ dout, int keep, const int* __restrict__ ids_restore, int B, int L,
-                                                                int d, float* __restrict__ dx, float* __restrict__ dmask) {
+                                                                int d, float* __restrict__ dx, float* __restrict__ dmask,
+                                                                float* __restrict__ unshuffle_partials) {
   __shared__ float4 red[4][64];
   const int nv = d >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void mae_unshuffle_bwd_kernel(const float* __r
   }
 }
 
-__global__ void mae_unshuffle_sum_kernel(int ngroups, int d, float* __restrict__ dmask) {
+__global__ void mae_unshuffle_sum_kernel(int ngroups, int d, float* __restrict__ dmask, const float* __restrict__ unshuffle_partials) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d) return;
   float t = 0.f;
@@ -170,9 +170,9 @@ __global__ void mae_unshuffle_sum_kernel(int ngroups, int d, float* __restrict__
 // ---- MAE reconstruction loss (models/mae.py:437-453, patchify :282-293; one input channel):
 // target[b][l][py*pw + px] = img[b][gy*ph + py][gx*pw + px], l = gy*gw + gx;  loss = sum_l mask * mean_p (pred - target)^2 / sum mask.
 // norm_pix (models/mae.py:443-446): target <- (target - mean_p target) / sqrt(var_p target + 1e-6), var unbiased (torch.var's default).
-// Pass 1: one wave per (b, l) row; every block leaves {sum mask * mean_p (.)^2, sum mask} in a device global and a one-wave launch adds the
-// blocks in block order (no float atomics: bit-reproducible) -> acc[0], acc[1].   Pass 2 (finalize): loss = acc[0] / acc[1].
-__device__ float mae_loss_partials[2 * 2048];
+// Pass 1: one wave per (b, l) row; every block leaves {sum mask * mean_p (.)^2, sum mask} in the caller's workspace ([2048][2] floats) and a
+// one-wave launch adds the blocks in block order (no float atomics: bit-reproducible) -> acc[0], acc[1].   Pass 2 (finalize): loss = acc[0] / acc[1].
+constexpr int MAE_LOSS_BLOCKS = 2048;
 
 // the patch's pixels of this lane (p = lane, lane + 64, ...) and, with norm_pix, its mean and 1 / sqrt(var + 1e-6) over the whole patch
 template <int MAXP>
@@ -198,7 +198,8 @@ constexpr int MAE_MAXP = 8;      // patches of up to 512 pixels (16 x 16 = 256, 
 
 __global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restrict__ pred, int64_t pred_seq_stride, int pred_row0,
                                                             const float* __restrict__ img, const float* __restrict__ mask,
-                                                            int B, int F, int T, int ph, int pw, int norm_pix) {
+                                                            int B, int F, int T, int ph, int pw, int norm_pix,
+                                                            float* __restrict__ mae_loss_partials) {
   __shared__ float red[8];
   const int gh = F / ph, gw = T / pw, L = gh * gw, P = ph * pw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256) void mae_loss_rows_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(64) void mae_loss_sum_kernel(int nblocks, float* __restrict__ acc, float* __restrict__ loss) {
+__global__ __launch_bounds__(64) void mae_loss_sum_kernel(int nblocks, float* __restrict__ acc, float* __restrict__ loss,
+                                                          const float* __restrict__ mae_loss_partials) {
   __shared__ float lanes[2][64];
   float a = 0.f, b = 0.f;
   for (int k = threadIdx.x; k < nblocks; k += 64) { a += mae_loss_partials[2 * k]; b += mae_loss_partials[2 * k + 1]; }
@@ -367,32 +369,37 @@ extern "C" int sa_mae_unshuffle_fwd(const float* x, int32_t keep, const float* m
   return 0;
 }
 
+extern "C" int64_t sa_mae_unshuffle_bwd_workspace_bytes(void) { return (int64_t)UNSH_GROUPS * UNSH_MAXD * sizeof(float); }
+extern "C" int64_t sa_mae_recon_loss_workspace_bytes(void) { return (int64_t)2 * MAE_LOSS_BLOCKS * sizeof(float); }
+
 extern "C" int sa_mae_unshuffle_bwd(const float* dout, int32_t keep, const int32_t* ids_restore, int32_t B, int32_t L, int32_t d, float* dx,
-                                    float* dmask_token, void* stream) {
+                                    float* dmask_token, float* ws, void* stream) {
   SA_CHECK_ARG(dout && ids_restore && dx && B > 0 && L > 0 && keep >= 0 && keep <= L && d > 0 && d % 4 == 0, "sa_mae_unshuffle_bwd: bad args");
+  SA_CHECK_ARG(!dmask_token || (ws && ((uintptr_t)ws & 15) == 0), "sa_mae_unshuffle_bwd: the mask-token gradient needs a 16-byte aligned workspace (sa_mae_unshuffle_bwd_workspace_bytes)");
   const int64_t rows = (int64_t)B * (L + 1);
   int gy = (int)((rows + 3) / 4);
   if (gy > UNSH_GROUPS) gy = UNSH_GROUPS;
   SA_CHECK_ARG(d <= UNSH_MAXD, "sa_mae_unshuffle_bwd: d = %d exceeds %d", d, UNSH_MAXD);
   hipLaunchKernelGGL(mae_unshuffle_bwd_kernel, dim3((d / 4 + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, dout, keep, ids_restore, B, L, d, dx,
-                     dmask_token);
-  if (dmask_token) hipLaunchKernelGGL(mae_unshuffle_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, d, dmask_token);
+                     dmask_token, ws);
+  if (dmask_token) hipLaunchKernelGGL(mae_unshuffle_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, d, dmask_token, ws);
   SA_LAUNCH_CHECK("sa_mae_unshuffle_bwd");
   return 0;
 }
 
 extern "C" int sa_mae_recon_loss_fwd(const float* pred, int64_t pred_seq_stride, int32_t pred_row0, const float* img, const float* mask, int32_t B, int32_t F, int32_t T, int32_t ph, int32_t pw,
-                                     int32_t norm_pix, float* acc2, float* loss, void* stream) {
+                                     int32_t norm_pix, float* acc2, float* loss, float* ws, void* stream) {
+  SA_CHECK_ARG(ws, "sa_mae_recon_loss_fwd: needs a workspace (sa_mae_recon_loss_workspace_bytes)");
   SA_CHECK_ARG(pred && img && mask && acc2 && loss && B > 0 && ph > 0 && pw > 0 && F >= ph && T >= pw && F % ph == 0 && T % pw == 0 &&
                    pred_row0 >= 0 && pred_seq_stride >= (int64_t)(pred_row0 + (F / ph) * (T / pw)) * ph * pw,
                "sa_mae_recon_loss_fwd: bad args (F, T must be multiples of the patch size; pred rows must fit the clip stride)");
   SA_CHECK_ARG(ph * pw <= 64 * MAE_MAXP && (!norm_pix || ph * pw > 1), "sa_mae_recon_loss_fwd: patches of at most %d pixels", 64 * MAE_MAXP);
   const int64_t rows = (int64_t)B * (F / ph) * (T / pw);
   int grid = (int)((rows + 3) / 4);
-  if (grid > 2048) grid = 2048;
+  if (grid > MAE_LOSS_BLOCKS) grid = MAE_LOSS_BLOCKS;
   hipLaunchKernelGGL(mae_loss_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, pred_seq_stride, pred_row0, img, mask, B, F, T, ph, pw,
-                     norm_pix);
-  hipLaunchKernelGGL(mae_loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, acc2, loss);
+                     norm_pix, ws);
+  hipLaunchKernelGGL(mae_loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grid, acc2, loss, ws);
   SA_LAUNCH_CHECK("sa_mae_recon_loss_fwd");
   return 0;
 }

@@ -29,6 +29,7 @@ SCHEMAS = {
     # (the matrices written are named by pointers inside `desc`; the schema marks desc so that the operator counts as one with a side effect)
     "transpose_bf16_batch": ("sa_transpose_bf16_batch", "(Tensor(a!) desc, int n_tiles) -> ()"),
     "cast_bf16": ("sa_cast_f32_to_bf16", "(Tensor src, Tensor(a!) dst) -> ()"),
+    "cast_f32_from_bf16": ("sa_cast_bf16_to_f32", "(Tensor src, Tensor(a!) dst) -> ()"),
     "colsum_bf16": ("sa_colsum_bf16", "(Tensor x, Tensor(a!) out, bool accumulate=False, int n_ranges=1, int range_stride=0) -> ()"),
     "layernorm_fwd": ("sa_layernorm_fwd", "(Tensor x, Tensor gamma, Tensor beta, float eps, *, Tensor(a!)? y_bf16=None, Tensor(b!)? y_f32=None, "
                       "Tensor(c!)? mean=None, Tensor(d!)? rstd=None) -> ()"),

@@ -32,20 +32,39 @@ def is_main_process():
     return get_rank() == 0
 
 
+def _ipc_env():
+    """RCCL across PROCESSES shares device buffers through IPC handles, and this host driver stack only supports the dmabuf form: without
+    HSA_ENABLE_IPC_MODE_LEGACY=0 the first communicator fails with `hipIpcGetMemHandle: invalid argument`.  The variable is read when the
+    HSA runtime initialises, i.e. at the first GPU call of the process, so it is set (if unset) when this module is imported and again in
+    init_from_env -- both ahead of any GPU call of the package; a launcher's or user's own value is never overridden."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+_ipc_env()
+
+
 def init_from_env(backend=None):
-    """torchrun-style initialisation (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
+    """torchrun-style initialisation (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), the counterpart of utils.init_distributed_mode
+    (utils/utils.py:335-361).  Returns (rank, local_rank, world).  Works the same under an external `torch.distributed.run` as under
+    bench.py's own child launcher: nothing here relies on the launcher having prepared the environment beyond torchrun's variables."""
     if "RANK" not in os.environ:
         return 0, 0, 1
+    _ipc_env()
     rank, local, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["WORLD_SIZE"])
     if not dist.is_initialized():
         backend = os.environ.get("SA_DIST_BACKEND", backend)    # e.g. gloo to rehearse several ranks on one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            local_dev = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_dev)
+            # bind the communicator to this rank's device at creation: without device_id torch guesses the device from the GLOBAL rank
+            # at the first collective ("Guessing device ID based on global rank. This can cause a hang ...")
+            kw["device_id"] = torch.device("cuda", local_dev)
             if RCCL_CUS > 0:                # see reserve_cus_for_collectives
                 os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CUS))
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, **kw)
     return rank, local, world
 
 
@@ -112,7 +131,7 @@ class GradSumParallel(nn.Module):
     whatever order the hooks fire in.  One backward per optimiser step, like DDP without no_sync(): a second backward before the
     step would all-reduce the first one's (already summed) gradients again (x W) and raises instead.  "Before the step" is tracked
     per wrapper: the end of a reduced backward marks the bucket views as holding rank-summed gradients; the mark is dropped by any
-    `torch.optim.Optimizer.step()` (a global post-step hook), by `grads_consumed()` for hand-written update loops, and per parameter
+    `torch.optim.Optimizer.step()` of an optimiser that holds one of the wrapper's parameters (a global post-step hook), by `grads_consumed()` for hand-written update loops, and per parameter
     when its `.grad` was replaced (`zero_grad(set_to_none=True)`, the default).
     """
 
@@ -147,9 +166,19 @@ class GradSumParallel(nn.Module):
             import weakref
             from torch.optim.optimizer import register_optimizer_step_post_hook
             GradSumParallel._live = weakref.WeakSet()
-            register_optimizer_step_post_hook(lambda *a, **k: [w.grads_consumed() for w in list(GradSumParallel._live)] and None)
+            register_optimizer_step_post_hook(GradSumParallel._after_optimizer_step)
         GradSumParallel._live.add(self)
         reserve_cus_for_collectives()
+
+    @staticmethod
+    def _after_optimizer_step(optimizer, *args, **kwargs):
+        """Global post-step hook: the step of `optimizer` consumes the summed gradients of the wrappers whose parameters IT holds -- a step
+        of an unrelated optimiser (another model, a probe, the predictor's own optimiser) leaves the other wrappers' guard armed
+        (any step in the process used to clear every wrapper's mark)."""
+        stepped = {id(p) for g in optimizer.param_groups for p in g["params"]}
+        for w in list(GradSumParallel._live):
+            if any(pid in stepped for pid in w._where):
+                w.grads_consumed()
 
     def grads_consumed(self):
         """The summed gradients have been applied (called by the global optimiser-step hook; call it yourself after a hand-written
@@ -198,7 +227,9 @@ class GradSumParallel(nn.Module):
             # would count the old sum W times
             raise RuntimeError("GradSumParallel: second backward before the optimiser step -- the gradients of the previous pass are "
                                "already summed over ranks and would be all-reduced again (gradient accumulation is not supported: "
-                               "one backward per step; after a hand-written update call .grads_consumed())")
+                               "one backward per step; after a hand-written update call .grads_consumed()).  The gradients are INVALID "
+                               "now (autograd has already added this pass's local gradient into the rank-summed one): zero_grad() "
+                               "before the next backward, do not step on them")
         if p.grad.data_ptr() != view.data_ptr():    # autograd allocated this gradient: move it into the bucket, keep the view
             view.copy_(p.grad)
             p.grad = view

@@ -4,8 +4,10 @@ signature as the reference's models/mae.py:166-469, so checkpoints and call site
 The nn.Module tree below only *owns parameters* (identical names / shapes / init families as the reference);
 no submodule's forward is ever called.  Compute is the explicit HIP schedule in engine.py / functional.py.
 The `vitc_*` variants put the ConvStem (convstem.py) in place of the patch projection.
-Not provided (out of this path's scope): stochastic depth, forward_attn / forward_viz; the learned positional embedding is
-used at its own patch grid only (no gradient through the bicubic resampling of other widths).
+Options: `norm_pix_loss` (models/mae.py:443-446) and the learned positional table (`--use_learned_pos_embd`, :198-199) are supported -- the
+table with its gradient THROUGH the bicubic resampling to other widths (:370-392: `_learned_pos` returns the interpolation as a matrix A,
+`TokensFn.backward` applies A^T to the summed token gradient; pinned by tests/golden/options.npz) for the plain patch projection; with the
+ConvStem the learned table is refused.  Not provided (out of this path's scope): stochastic depth, forward_attn / forward_viz.
 """
 from functools import partial
 

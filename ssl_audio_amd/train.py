@@ -233,15 +233,27 @@ def _empty_groups(lr, wd, betas=(0.9, 0.999), eps=1e-8):
 
 class GradSync:
     """Gradient SUM all-reduce over ranks, bucketed per transformer block and overlapped with backward on a side
-    HIP stream (collective site C3).  Buckets are contiguous ranges of FlatState.grads."""
+    HIP stream (collective site C3).  Buckets are contiguous ranges of FlatState.grads.
 
-    def __init__(self, flat, bucket_bytes=64 << 20, min_block_bytes=1 << 20):
+    grad_dtype "bf16" (default: $SA_GRAD_DTYPE, else "fp32"): a range travels as bf16 -- cast into a bf16 staging buffer on the side
+    stream (sa_cast_f32_to_bf16), all-reduced there at half the bytes (187 instead of 374 MB per step and GPU for ViT-B; xGMI rings are
+    per-link bound), widened back into the fp32 gradient buffer (sa_cast_bf16_to_f32) -- the moments and the update stay fp32.  The
+    reference's DDP does the same under its fp16 autocast (gradient buckets in the parameters' reduced type); here it is an option
+    because the sum of W bf16-rounded shares differs from the fp32 sum by ~1e-3 relative (tests/test_dp_gloo.py bounds it)."""
+
+    def __init__(self, flat, bucket_bytes=64 << 20, min_block_bytes=1 << 20, grad_dtype=None):
+        import os
+        grad_dtype = grad_dtype or os.environ.get("SA_GRAD_DTYPE", "fp32")
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_dtype must be 'fp32' or 'bf16', got {grad_dtype!r}")
+        self.grad_dtype = grad_dtype
         self.flat = flat
         self.world = sdist.get_world_size()
         self.active = sdist.collectives_active()
         self.stream = torch.cuda.Stream() if (self.active and flat.grads.is_cuda) else None
         self.pending = []
         self.bucket_bytes = bucket_bytes
+        self._stage = None         # bf16 image of flat.grads' trainable range (grad_dtype bf16), allocated at the first exchange
         # a block's un-decayed vectors (LayerNorm weights, biases: a few KB) are NOT worth a collective of their own -- twelve
         # latency-bound all-reduces per step, each holding CUs next to the backward's GEMMs: runs below this size are left to finish(),
         # where the whole un-decayed region (contiguous in the flat buffer) goes out as one range
@@ -284,14 +296,33 @@ class GradSync:
     def _launch(self, lo, hi):
         self._ready_ranges.append((lo, hi))
         view = self.flat.grads[lo:hi]
+        if self.grad_dtype == "bf16":
+            if lo % 8:                                                # (FlatState pads every parameter to 8 elements: ranges start 16-byte aligned in bf16)
+                raise RuntimeError(f"GradSync: gradient range [{lo}, {hi}) does not start on an 8-element boundary")
+            if self._stage is None:
+                self._stage = torch.empty(self.flat.n_train, dtype=torch.bfloat16, device=self.flat.grads.device)
+            stage = self._stage[lo:hi]
         if self.stream is None:
-            sdist.all_reduce_sum_(view)
+            if self.grad_dtype == "bf16":
+                ops.cast_bf16(view, stage)
+                sdist.all_reduce_sum_(stage)
+                ops.cast_f32_from_bf16(stage, view)
+            else:
+                sdist.all_reduce_sum_(view)
             return
         ev = torch.cuda.Event()
         ev.record()
         self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
-            self.pending.append(torch.distributed.all_reduce(view, async_op=True))
+            if self.grad_dtype == "bf16":
+                # cast -> all-reduce -> widen, all ordered on the side stream (work.wait() makes the side STREAM wait, not the host); the
+                # next range's cast queues behind this range's collective, which RCCL would serialise anyway
+                ops.cast_bf16(view, stage)
+                work = torch.distributed.all_reduce(stage, async_op=True)
+                work.wait()
+                ops.cast_f32_from_bf16(stage, view)
+            else:
+                self.pending.append(torch.distributed.all_reduce(view, async_op=True))
 
     def finish(self):
         """Reduce whatever no block hook covered (head, cls token, final norm, ...) and join the side stream."""
@@ -321,7 +352,7 @@ class BarlowTwinsTrainer:
     unmasked encoder, one BT term between them."""
 
     def __init__(self, cfg, device, mode="bt", batch_per_rank=None, clip_samples=160000, seed=0, from_waveform=True,
-                 ema_beta=0.99):
+                 ema_beta=0.99, grad_dtype=None):
         self.cfg, self.device, self.mode = cfg, device, mode
         self.world = sdist.get_world_size()
         self.B = batch_per_rank or cfg.batch_size // self.world
@@ -337,12 +368,12 @@ class BarlowTwinsTrainer:
                                       "L + 2 pieces, which only lines up for L = 0")
         self.criterion = BarlowTwinsLoss(cfg, ncrops=self.L + 2).to(device)
         sdist.reserve_cus_for_collectives()
-        self.sync = self.flat.sync = GradSync(self.flat)
+        self.sync = self.flat.sync = GradSync(self.flat, grad_dtype=grad_dtype)
         self.predictor = self.target = self.flat_pred = self.flat_target = None
         if mode == "byol":
             self.predictor = BarlowTwinsPredictor(cfg.projector_out_dim, use=True).to(device)
             self.flat_pred = FlatState(list(self.predictor.named_parameters()), device)
-            self.sync_pred = self.flat_pred.sync = GradSync(self.flat_pred)
+            self.sync_pred = self.flat_pred.sync = GradSync(self.flat_pred, grad_dtype=grad_dtype)
             self.target = MultiCropWrapper(ModelWrapper(cfg), BarlowTwinsHead(cfg, _feature_dim(cfg))).to(device)
             self.target.load_state_dict(self.online.state_dict())
             for p in self.target.parameters():

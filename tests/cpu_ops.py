@@ -20,6 +20,11 @@ def cast_bf16(src, dst=None):
     return out
 
 
+def cast_f32_from_bf16(src, dst):
+    dst.copy_(src.to(F32))
+    return dst
+
+
 def pick_split_k(M, N, K, cu_count=None, tile=128):
     return 1
 

@@ -44,3 +44,54 @@ def test_self_launch_returns_the_childs_exit_code():
     assert r.returncode != 0
     assert "starting" in r.stderr and "torch.distributed.run" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_external_launcher_dry_run_two_gloo_ranks():
+    """VERDICT r4 #2 iv: bench.py under an EXTERNAL `torch.distributed.run` (the driver's way of launching N > 1) with nothing prepared
+    beyond torchrun's own variables: the ranks rendezvous through dist.init_from_env, which also sets HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL
+    across processes needs dmabuf IPC on this driver; bench.py's own child launcher used to be the only place that set it), rank 0 prints
+    one JSON line with the launch fields and no value.  gloo on CPU: no GPU is touched."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    e = {k: v for k, v in _env().items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    e.update(SA_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry_run", "--grad_dtype", "bf16"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                                    # rank 0 only
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["dry_run"] is True and j["value"] is None and j["n_gpus"] == 2
+    assert c["dist_world"] == 2 and c["dist_backend"] == "gloo" and c["launcher"] == "torch.distributed.run" and c["parallelism"] == "dp2"
+    assert c["max_rank_plus_1"] == 2.0                                                  # the MAX all-reduce really crossed the ranks
+    assert c["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and c["env"]["MASTER_ADDR"] == "127.0.0.1" and c["grad_dtype"] == "bf16"
+
+
+def test_a_user_value_of_the_ipc_variable_is_kept_and_world_mismatch_is_refused_in_dry_run():
+    e = dict(_env(), HSA_ENABLE_IPC_MODE_LEGACY="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry_run"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    e = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29433", SA_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry_run"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_is_refused_from_a_profiled_process():
+    """under rocprofv3 the profiler's injected library has already initialised the GPU in the parent, so starting the ranks from
+    there is the forbidden fork + exec out of a GPU-initialised process: bench.py detects the profiler's environment and exits non-zero
+    before spawning anything (`--dry_launch` still only prints)."""
+    for marker in ({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"}, {"ROCPROFILER_SOMETHING": "1"},
+                   {"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so.1"}):
+        e = dict(_env(), **marker)
+        if "LD_PRELOAD" in marker:
+            e.pop("LD_PRELOAD")                       # (a non-existent preload would only make the loader complain; the check reads the variable)
+            e["ROCPROF_OUTPUT_PATH"] = "/tmp/x"
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--no_cpu_baseline"], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 3 and "refusing to self-launch" in r.stderr and "starting" not in r.stderr, (marker, r.stderr[-500:])
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry_launch"], env=dict(_env(), ROCPROF_OUTPUT_PATH="/tmp/x"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "launch" in r.stdout

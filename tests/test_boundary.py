@@ -209,7 +209,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
         "sa_attention_fwd": lambda: h.sa_attention_fwd(one, 8, 2304, 768, 12, 300, 0, 0.125, one, 768, null, null),
         "sa_gather_rows": lambda: h.sa_gather_rows(one, 0, 0, one, 4, one, 0, 0, 2, 6, null),
         "sa_mae_unshuffle_fwd": lambda: h.sa_mae_unshuffle_fwd(one, 9, one, one, one, 2, 8, 64, one, null),
-        "sa_mae_recon_loss_fwd": lambda: h.sa_mae_recon_loss_fwd(one, 10, 1, one, one, 2, 60, 96, 16, 16, 0, one, one, null),
+        "sa_mae_recon_loss_fwd": lambda: h.sa_mae_recon_loss_fwd(one, 10, 1, one, one, 2, 60, 96, 16, 16, 0, one, one, one, null),
         "sa_mean_tokens_fwd": lambda: h.sa_mean_tokens_fwd(one, 2, 1, 64, one, null),
     }
     for name, call in cases.items():
@@ -252,7 +252,8 @@ def test_custom_ops_cover_every_compute_entry_point():
     covered = {sym for sym, _ in custom_ops.SCHEMAS.values()}
     plain = {s for s in _lib.header_symbols() if s not in covered}
     assert plain == {"sa_abi_version", "sa_last_error", "sa_device_info", "sa_set_cu_budget", "sa_set_dynamic_tiles", "sa_bn_tall_workspace_bytes",
-                     "sa_gemm_colsum_workspace_bytes", "sa_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes"}, plain
+                     "sa_gemm_colsum_workspace_bytes", "sa_colsum_workspace_bytes", "sa_gemm_splitk_workspace_bytes", "sa_layernorm_bwd_workspace_bytes",
+                     "sa_bt_loss_workspace_bytes", "sa_mae_recon_loss_workspace_bytes", "sa_mae_unshuffle_bwd_workspace_bytes"}, plain
     assert covered <= set(_lib.header_symbols())
     for name, (sym, schema) in custom_ops.SCHEMAS.items():
         op = getattr(torch.ops.ssl_audio, name).default

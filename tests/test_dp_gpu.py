@@ -46,16 +46,18 @@ KEYS = ["backbone.encoder.encoder.cls_token", "backbone.encoder.encoder.blocks.0
         "head.projector.3.weight", "head.projector.1.running_var"]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, grad_dtype="fp32"):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                          SA_DIST_BACKEND="gloo")
+                          SA_DIST_BACKEND="gloo", SA_GRAD_DTYPE=grad_dtype)
         from ssl_audio_amd import dist as sdist
         sdist.init_from_env("gloo")
         tr, views = _make(16, rank, world)
+        assert tr.sync.grad_dtype == grad_dtype and tr.sync.active
         loss = float(tr.step_views(views))
         torch.cuda.synchronize()
+        assert (tr.sync._stage is not None) == (grad_dtype == "bf16")
         sd = tr.online.state_dict()
         q.put((rank, loss, {k: sd[k].detach().float().cpu().numpy() for k in KEYS}, None, _grads(tr)))
         torch.distributed.barrier()
@@ -65,12 +67,15 @@ def _worker(rank, world, port, q):
         q.put((rank, None, None, repr(e) + traceback.format_exc()))
 
 
-def test_two_ranks_equal_single_process():
+@pytest.mark.parametrize("grad_dtype", ["fp32", "bf16"])
+def test_two_ranks_equal_single_process(grad_dtype):
+    """grad_dtype bf16 (VERDICT r4 #2 iii): the per-block gradient ranges travel as bf16 staging buckets (sa_cast_f32_to_bf16 -> all-reduce ->
+    sa_cast_bf16_to_f32 on the side stream); same bounds as the fp32 exchange (the gradients are bf16-noisy to begin with)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, grad_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -332,6 +337,7 @@ def test_rccl_call_sites_with_one_rank():
     # SA_DETERMINISTIC=1: split-K sums in slice order.  The loss after three AdamW steps at batch 8 amplifies the fp32 rounding of an
     # arbitrary atomic summation order to a few 1e-3 (Adam's first updates are sign-like), which would mask what this test is about.
     det = dict(os.environ, SA_DETERMINISTIC="1")
+    det.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)     # an EXTERNAL launcher prepares nothing: dist.init_from_env sets the dmabuf IPC mode itself
     plain = subprocess.run([sys.executable] + common, cwd=ROOT, env=det, capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stderr[-2000:]
     env = dict(det, SA_DIST_FORCE="1")
@@ -343,3 +349,12 @@ def test_rccl_call_sites_with_one_rank():
     a, b = json.loads(plain.stdout.strip().splitlines()[-1]), json.loads(lines[0])
     assert b["n_gpus"] == 1 and b["config"]["parallelism"] == "dp1"
     assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"])
+    assert b["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and b["config"]["dist_backend"] == "nccl" and b["config"]["grad_dtype"] == "fp32"
+    assert "Guessing device ID" not in dist.stderr                       # init_process_group got device_id (VERDICT r4 #2 ii)
+    # the same rehearsal with bf16 gradient buckets: one rank, so the "sum" is one bf16 rounding of every gradient
+    d16 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port())] + common + ["--gpus", "1", "--grad_dtype", "bf16"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert d16.returncode == 0, d16.stderr[-2000:]
+    c = json.loads([l for l in d16.stdout.splitlines() if l.strip()][0])
+    assert c["config"]["grad_dtype"] == "bf16" and abs(c["config"]["loss"] - a["config"]["loss"]) <= 2e-2 * abs(a["config"]["loss"])

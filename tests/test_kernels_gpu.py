@@ -780,3 +780,41 @@ def test_custom_ops_reach_the_same_kernels(dev):
     ops.colsum_bf16(y, c1); ops.colsum_bf16(y, c2); torch.ops.ssl_audio.colsum_bf16(y, c3)
     assert torch.equal(c1, c2) and torch.equal(c1, c3)
     assert float((c1.double().cpu() - y.double().sum(0).cpu()).abs().max()) < 1e-2
+
+
+def test_cast_bf16_to_f32_and_back(dev):
+    """sa_cast_bf16_to_f32 (ABI v6, the way back from a bf16 gradient bucket): exact widening, ragged tail, round trip with sa_cast_f32_to_bf16."""
+    for n in (8, 4096, 1000003):
+        x = torch.randn(n, device=dev) * 3.0
+        h = ops.cast_bf16(x)
+        assert torch.equal(h, x.to(torch.bfloat16))
+        y = torch.full((n,), 7.0, device=dev)
+        ops.cast_f32_from_bf16(h, y)
+        assert torch.equal(y, h.float())
+    with pytest.raises(ValueError):
+        ops.cast_f32_from_bf16(h, torch.empty(5, device=dev))
+
+
+def test_partial_sum_workspaces_are_per_stream(dev):
+    """the block partials of sa_bt_loss_grad / sa_mae_recon_loss_fwd / sa_mae_unshuffle_bwd are the CALLER's workspace (ABI v6),
+    and `ops` keeps one per stream: loss launches issued back to back on two streams (the producer kernel of one may run between the
+    producer and the adding kernel of the other) each get their own sums."""
+    D = 256
+    g = torch.Generator(device=dev).manual_seed(3)
+    cs = [torch.randn(D, D, device=dev, generator=g) * (k + 1) for k in range(2)]
+    ref = []
+    for c in cs:
+        off = c - torch.diag(torch.diag(c))
+        ref.append(float(((torch.diag(c) - 1) ** 2).sum() + 0.005 * (off ** 2).sum()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    losses = [torch.zeros(1, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(50):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                ops.bt_loss_grad(cs[k], 1.0, 0.005, False, losses[k])
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert abs(float(losses[k]) - ref[k]) <= 2e-5 * abs(ref[k]), (it, k, float(losses[k]), ref[k])
+    keys = [k for k in ops._WORKSPACES if k[1] == "bt_loss"]
+    assert len({k[2] for k in keys}) >= 2
