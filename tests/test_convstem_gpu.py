@@ -20,7 +20,9 @@ def dev():
 
 
 def T(a, dev=None, dtype=torch.float32):
-    t = torch.from_numpy(np.asarray(a)).to(dtype)
+    # a COPY: the golden fixtures are cached per session, and the oracle's optimiser steps update their tensors in place -- a tensor that
+    # shares the fixture's memory would hand every later reader of the fixture the trained weights (found in round 5)
+    t = torch.tensor(np.asarray(a), dtype=dtype)
     return t.to(dev) if dev is not None else t
 
 

@@ -14,7 +14,7 @@ from oracle import vit as ovit
 
 
 def T(a, dtype=torch.float32):
-    return torch.from_numpy(np.asarray(a)).to(dtype)
+    return torch.tensor(np.asarray(a), dtype=dtype)            # (a copy: the cached fixtures must never be written through a tensor)
 
 
 # ----------------------------------------------------------------------------- BT loss
