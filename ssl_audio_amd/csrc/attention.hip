@@ -18,6 +18,19 @@
 #include <type_traits>
 #include "../../include/ssl_audio_hip.h"
 
+// -DSA_ATTN_DBG=1 (A/B builds only, scripts/ab_build.sh + scripts/diag/attn_timeline.py): waves 0 and 7 of every backward workgroup leave
+// cycle stamps of their phases and the id of the CU they ran on in a buffer handed in through sa_attn_dbg_set.
+#ifndef SA_ATTN_DBG
+#define SA_ATTN_DBG 0
+#endif
+#if SA_ATTN_DBG
+__device__ unsigned long long* sa_attn_dbg_ptr = nullptr;
+extern "C" int sa_attn_dbg_set(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sa_attn_dbg_ptr), &buf, sizeof(buf)); }
+#define ATTN_STAMP(k) { __builtin_amdgcn_sched_barrier(0); dbg_t[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ATTN_STAMP(k)
+#endif
+
 namespace {
 
 constexpr int HD = 64;          // head dim
@@ -210,8 +223,8 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
 // The version before this one re-staged Q / dO from global and fetched the pass-B fragments from global as well: 320 KB of reads
 // per head instead of 160, and with the compute loops removed it still took 70 % of its time -- the kernel was bound by that traffic.
 template <int NMAX>
-__global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N,
-                                                          int nq, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, int64_t total_rows, int ld, int C, int H, int N_arg,
+                                                          int nq_arg, float scale, const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                           int ldo, const float* __restrict__ lse, bf16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IMG = NMAX * HD * 2;                 // NMAX = 256: 2 x 32 KiB + statistics = 66 KiB -> two workgroups per CU
@@ -222,29 +235,54 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   char* Dimg = smem + IMG;                           // dO
   float* lse_s = reinterpret_cast<float*>(smem + 2 * IMG);   // -lse in log2 units / -delta per query: the initial accumulators of
   float* del_s = lse_s + NMAX;                                // the S and dP chains of pass B
-  const int lane = threadIdx.x & 63;
+  const int lane_id = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  // The body is a loop over (sequence, head) units so that the grid can be persistent (SA_ATTN_BWD_PERSIST=1: two workgroups per CU walk
+  // the list with the stride of the grid).  Measured in round 5 (scripts/diag/attn_timeline.py, profiles/r05_attn_timeline.txt): with one
+  // workgroup per head a CU's slot stays empty for 5 - 8 k cycles between a workgroup's last store and its successor's entry -- 5 k of
+  // them because wave 7 ends that much later than wave 0 (LDS is released when the LAST wave ends), 2 - 3 k dispatch -- which the
+  // persistent walk only trades for the same skew at its loop barrier, while its static share (6 heads per workgroup, lives spread
+  // 47 - 97 k cycles) ends on the slowest workgroup: 340 - 344 us against 307 - 312 us for this kernel with one workgroup per head
+  // (HEAD's kernel: 317 - 324 us, same box).  Default: one head per workgroup -- the loop then runs once.
+  const int n_units = (int)(total_rows / N_arg) * H;
+#pragma clang loop unroll(disable)
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+  // Everything derived from the lane id (LDS offsets of the fragment reads, ...) is re-derived per head from an opaque copy: hoisted out of
+  // the loop those values stay live across the prologue's 48 registers of Q / dO / O fragments and the kernel spills (it runs at the
+  // 128-register cap of four waves per SIMD: 300 bytes of scratch per lane and 443 us instead of 317 when the compiler was left to it).
+  int lane = lane_id;
+  asm volatile("" : "+v"(lane));
+  const int g = lane >> 4, c = lane & 15;
+  // ... and so are the sequence length and the query count: as loop invariants every `tile < count` test of the unrolled passes is
+  // hoisted into its own SGPR pair (~25 of them), the scalar file overflows and the prologue's fragment loads end up in scratch
+  int N = N_arg, nq = nq_arg;
+  asm volatile("" : "+s"(N), "+s"(nq));
+  const int s = unit / H, h = unit - s * H;
   const int64_t row_base = (int64_t)s * N;
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + row_base * ld, (uint32_t)(((total_rows - row_base - 1) * ld + 3 * C) * 2));
   const __amdgpu_buffer_rsrc_t rd = make_rsrc(dout + row_base * ldo, (uint32_t)(((total_rows - row_base - 1) * ldo + C) * 2));
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(o + row_base * ldo, (uint32_t)(((total_rows - row_base - 1) * ldo + C) * 2));
 
-  const int g = lane >> 4, c = lane & 15;
   const int nkt = (N + 15) >> 4;                       // 16-row tiles holding real rows
   const int nks = (N + 31) >> 5;                       // 32-row steps: tiles [0, 2 * nks) exist in the images (rows >= N hold finite junk)
   const int nqt = (nq + 15) >> 4, nqs = (nq + 31) >> 5;   // queries >= nq carry no upstream gradient (CLS-only last block)
   const float c2 = scale * 1.44269504088896340736f;    // p = exp(scale*s - lse) = exp2(c2*s - lse*log2e)
+#if SA_ATTN_DBG
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  ATTN_STAMP(0)
 
   stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane, NW_BWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane, NW_BWD);
   // own query tiles: Q, dO (kept until they become the pass-B images) and O (only for delta).  Rows past N read the next
   // sequence or zeros -- finite either way, and every use of them is multiplied by p = 0 or never stored.
-  bf16x8 qf[NT][2], df[NT][2];
-  float nl[NT], nd[NT];                                // -lse (log2 units), -delta of query tile j, row c
+  // (every conditionally loaded array starts defined: inside the head loop an undefined path would be merged with the PREVIOUS head's
+  // registers, i.e. 64 fragment registers would stay live across the whole loop body)
+  bf16x8 qf[NT][2] = {}, df[NT][2] = {};
+  float nl[NT] = {}, nd[NT] = {};                      // -lse (log2 units), -delta of query tile j, row c
   {
-    bf16x8 of[NT][2];
-    float ls[NT];
+    bf16x8 of[NT][2] = {};
+    float ls[NT] = {};
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int t = wave + j * NW_BWD;
@@ -277,8 +315,10 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
       }
     }
   }
+  ATTN_STAMP(1)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  ATTN_STAMP(2)
 
   // per-lane LDS offsets, loop invariant: tile bases are multiples of 16 rows, so (row & 7) never depends on the tile
   const int rf0 = c * 128 + ((g ^ (c & 7)) << 4), rf1 = c * 128 + (((4 + g) ^ (c & 7)) << 4);       // row_frag, k-step 0 / 1
@@ -305,8 +345,10 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     if (qt >= nkt) continue;
     const int query = qt * 16 + c;
     f32x4 acc[4];
+    float z0 = 0.f;
+    asm volatile("" : "+v"(z0));                             // (an opaque zero: constant zero vectors get hoisted out of the head loop and held in 48 registers)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{z0, z0, z0, z0};
     if (qt < nqt) {                                          // dQ of an un-queried tile is exactly zero
       // Q prescaled by scale * log2(e): with -lse as the chain's initial accumulator the scores come out as S' = c2 s - lse, and
       // dP' = dP - delta likewise, so p = exp2(S') and dS = p * dP' need no further VALU
@@ -353,8 +395,9 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     }
   }
 
+  ATTN_STAMP(3)
   // ------------------------------------------------------------------ hand-over: K, V fragments out of the images, Q, dO fragments in
-  bf16x8 kf[NT][2], vf[NT][2];
+  bf16x8 kf[NT][2] = {}, vf[NT][2] = {};
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int kt = wave + j * NW_BWD;
@@ -378,6 +421,7 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  ATTN_STAMP(4)
 
   // ------------------------------------------------------------------ pass B: dK, dV (wave owns key tiles)
 #pragma unroll
@@ -388,8 +432,10 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
     const bf16x8 kf0 = scale_frag(kf[j][0], c2), kf1 = scale_frag(kf[j][1], c2);
     const bf16x8 vf0 = vf[j][0], vf1 = vf[j][1];
     f32x4 dk[4], dv[4];
+    float z1 = 0.f;
+    asm volatile("" : "+v"(z1));
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{z1, z1, z1, z1};
 #pragma unroll
     for (int qs = 0; qs < NMAX / 32; ++qs) {
       if (qs >= nqs) continue;
@@ -427,6 +473,20 @@ __global__ __launch_bounds__(64 * NW_BWD, NMAX == 256 ? 4 : 2) void attn_bwd_ker
         *reinterpret_cast<u32x2*>(vrow + dt * 16 + 4 * g) = u32x2{cvt_pk(dv[dt][0], dv[dt][1]), cvt_pk(dv[dt][2], dv[dt][3])};
       }
     }
+  }
+#if SA_ATTN_DBG
+  ATTN_STAMP(5)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(6)
+  if (sa_attn_dbg_ptr && lane == 0 && (wave == 0 || wave == NW_BWD - 1)) {
+    // HW_REG_HW_ID (4): wave [3:0] simd [5:4] pipe [7:6] cu [11:8] sh [12] se [15:13];  HW_REG_XCC_ID (20): xcc [3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    unsigned long long* o_ = sa_attn_dbg_ptr + ((size_t)unit * 2 + (wave ? 1 : 0)) * 8;
+    for (int k = 0; k < 7; ++k) o_[k] = dbg_t[k];
+    o_[7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
+  __syncthreads();                                   // the next head's K / V rows replace the Q / dO images pass B has been reading
   }
 }
 
@@ -482,6 +542,19 @@ extern "C" int sa_attention_fwd(const void* qkv, int64_t rows, int64_t ld, int32
   return 0;
 }
 
+// workgroups of the persistent backward: `per_cu` per CU (what its LDS allows), never more than there are heads
+static int attn_bwd_grid(int units, int per_cu) {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  static const char* env = getenv("SA_ATTN_BWD_PERSIST");          // (1: persistent walk, measured slower: see the kernel's comment)
+  if (!(env && env[0] == '1')) return units;
+  return units < per_cu * cus ? units : per_cu * cus;
+}
+
 extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32_t C, int32_t H, int32_t N, int32_t n_query, float scale,
                                 const void* out, const void* dout, int64_t ldo, const float* lse, void* dqkv, void* stream) {
   if (n_query <= 0 || n_query > N) n_query = N;
@@ -496,7 +569,7 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       configured = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+    hipLaunchKernelGGL(attn_bwd_kernel<256>, dim3(attn_bwd_grid(S * H, 2)), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
                        scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   } else {
     constexpr int lds = 2 * 512 * HD * 2 + 2 * 512 * (int)sizeof(float);
@@ -508,7 +581,7 @@ extern "C" int sa_attention_bwd(const void* qkv, int64_t rows, int64_t ld, int32
       }
       configured = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel<512>, dim3(S * H), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
+    hipLaunchKernelGGL(attn_bwd_kernel<512>, dim3(attn_bwd_grid(S * H, 1)), dim3(64 * NW_BWD), lds, (hipStream_t)stream, (const bf16_t*)qkv, rows, (int)ld, C, H, N, n_query,
                        scale, (const bf16_t*)out, (const bf16_t*)dout, (int)ldo, lse, (bf16_t*)dqkv);
   }
   SA_LAUNCH_CHECK("sa_attention_bwd");

@@ -213,9 +213,18 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4&
 // tail is ISSUE-bound (cdna_hip_programming.md T21).  Staging the tile through 9 KiB of this wave's LDS turns it
 // into 8 x 16-byte stores per lane that write whole 128-byte row segments.  fp32 outputs already store 16 B per lane.
 constexpr int EPI_STRIDE = 144;                 // bytes per staged row: 64 bf16 + 16 B pad (16-byte aligned rows)
+// XOR key of the swizzled (128-byte row) scratch.  The row-per-lane side moves 8 bytes per lane (ds_write_b64 / ds_read_b64: 32 lanes per
+// LDS cycle = rows c = 0..15 x two lanes): two rows of equal parity share their 32 banks, so the 8 rows of one parity must get 8
+// DIFFERENT chunk positions.  (row >> 1) & 7 does that; the key of rounds 1-4, row & 7, gave rows c and c + 8 the same position -- a
+// 2-way conflict on every such access, 12 % of the persistent kernel's LDS-active cycles (profiles/r04_gemm_pmc.txt; VERDICT r4 #4a).
+// The 16-byte side (16 lanes per cycle = two whole rows) is conflict-free under any key.
+#ifndef SA_EPI_KEY_OLD
+#define SA_EPI_KEY_OLD 0                      // (A/B builds only: scripts/ab_build.sh)
+#endif
+__device__ __forceinline__ int epi_key(int row) { return SA_EPI_KEY_OLD ? (row & 7) : ((row >> 1) & 7); }
 constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
 
-// SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by (row & 7),
+// SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by epi_key(row),
 // exactly 8 KiB per wave -- four waves fit one 32 KiB pipeline stage (the persistent kernel stages its epilogue in the
 // stage it has just finished reading while the other stage already receives the next tile).
 // NI = 16-row groups handled per call: 4 (a 64-row block, 8 KiB of scratch) or 2 (32 rows, 4 KiB: the phased kernel, whose
@@ -241,7 +250,7 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
       }
       const int row = i * 16 + c;
       if constexpr (SWZ)
-        *reinterpret_cast<bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8) = h;
+        *reinterpret_cast<bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ epi_key(row)) << 4) + (g & 1) * 8) = h;
       else
         *reinterpret_cast<bf16x4*>(wlds + row * EPI_STRIDE + (j * 16 + 4 * g) * 2) = h;
     }
@@ -259,7 +268,7 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
 #pragma unroll
     for (int it = 0; it < 2 * NI; ++it) {
       const int r = it * 8 + (lane >> 3);
-      const uint4 q = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
+      const uint4 q = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ epi_key(r)) << 4))
                           : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
       const u32x4 val = {q.x, q.y, q.z, q.w};
       // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels
@@ -273,7 +282,7 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
   for (int it = 0; it < 2 * NI; ++it) {
     const int r = it * 8 + (lane >> 3);
     const int m = m_base + r;
-    const uint4 val = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4))
+    const uint4 val = SWZ ? *reinterpret_cast<const uint4*>(wlds + r * 128 + ((ch ^ epi_key(r)) << 4))
                           : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
     if (m < p.M) {
       const int64_t orow = (int64_t)m + m / p.row_group + 1;
@@ -309,7 +318,7 @@ __device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds
     uint4 val = make_uint4(0u, 0u, 0u, 0u);
     if (pre) val = pre[it];
     else if (m < p.M) val = *reinterpret_cast<const uint4*>(src + (int64_t)m * ld + n_base + ch * 8);
-    *reinterpret_cast<uint4*>(wlds + r * 128 + ((ch ^ (r & 7)) << 4)) = val;
+    *reinterpret_cast<uint4*>(wlds + r * 128 + ((ch ^ epi_key(r)) << 4)) = val;
   }
 }
 
@@ -396,7 +405,7 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
       const int row = i * 16 + c;                       // rows past M were staged as zeros: their products are zero, nothing is stored
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8);
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(wlds + row * 128 + (((j * 2 + (g >> 1)) ^ epi_key(row)) << 4) + (g & 1) * 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] * alpha * (kind == 5 ? bf2f(h[r]) : dgelu_f(bf2f(h[r])));
       }

@@ -16,6 +16,26 @@ def off_diagonal(x):
     return x.flatten()[:-1].view(n - 1, n + 1)[:, 1:].flatten()
 
 
+def _cat_crops(crops):
+    """torch.cat(crops) -- without the copy when the crops ARE one tensor already: `BatchedPairAugment` writes the two global views of a
+    batch as [2, B, 1, F, T], so views[0] and views[1] are adjacent slices of one allocation and their concatenation is a view of it
+    (65 MB per ViT-B step not copied; VERDICT r4 #7).  Anything else (other strides, gaps, autograd history) takes torch.cat."""
+    if len(crops) == 1:
+        return crops[0]
+    first = crops[0]
+    ok = first.is_contiguous() and not first.requires_grad and first.dim() >= 1
+    if ok:
+        step = first.numel() * first.element_size()
+        for k, c in enumerate(crops):
+            if (c.shape != first.shape or c.dtype != first.dtype or c.device != first.device or not c.is_contiguous() or c.requires_grad
+                    or c.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or c.data_ptr() != first.data_ptr() + k * step):
+                ok = False
+                break
+    if not ok:
+        return torch.cat(crops)
+    return first.as_strided((len(crops) * first.shape[0],) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
+
+
 class MultiCropWrapper(nn.Module):
     """Same-resolution crops are concatenated and run through the backbone together; the head sees all outputs."""
 
@@ -33,7 +53,7 @@ class MultiCropWrapper(nn.Module):
         for end in range(1, len(x) + 1):
             if end < len(x) and widths[end] == widths[start]:
                 continue
-            batch = torch.cat(x[start:end]) if end - start > 1 else x[start]
+            batch = _cat_crops(x[start:end])
             _out = self.backbone(batch, **kwargs)
             if isinstance(_out, tuple):
                 recon_loss = _out[1] if recon_loss is None else recon_loss + _out[1]
