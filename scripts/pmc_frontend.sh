@@ -2,7 +2,7 @@
 # PMC counters of the frontend / augmentation kernels (scripts/bench_frontend.py), one rocprofv3 pass per counter group.
 #   usage (GPU box): bash scripts/pmc_frontend.sh OUTDIR
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/r04/pmc_fe}; mkdir -p $O
+O=${1:-gpurun_out/r05/pmc_fe}; mkdir -p $O
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_IDX_ACTIVE" \

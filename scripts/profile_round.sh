@@ -5,7 +5,7 @@
 #   PMC of the GEMM families, the per-block GEMM table, the hipBLASLt bar and the attention table.
 #   usage: bash scripts/profile_round.sh [workload ...]        (default: all four)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${SA_ROUND:-r04}                      # file-name prefix of the round's artefacts (profiles/${R}_*)
+R=${SA_ROUND:-r05}                      # file-name prefix of the round's artefacts (profiles/${R}_*)
 O=gpurun_out/$R; mkdir -p $O
 WL=${@:-vit_base_bt_10s vit_tiny_bt_10s vit_base_byol_10s vit_large_mae_10s}
 if [ $# -eq 0 ]; then rm -f $O/gemm_traffic.json; else cp profiles/${R}_gemm_traffic.json $O/gemm_traffic.json; fi   # named workloads: refresh their entries only
@@ -41,7 +41,8 @@ python3 scripts/bench_gemm.py > $O/bench_gemm_block.txt 2>&1
 python3 scripts/bench_gemm_torch.py > $O/bench_gemm_hipblaslt.txt 2>&1
 python3 scripts/bench_attn.py > $O/bench_attn.txt 2>&1; python3 scripts/bench_attn.py 501 >> $O/bench_attn.txt 2>&1
 for f in $O/bench_gemm_block.txt $O/bench_gemm_hipblaslt.txt $O/bench_attn.txt; do tail -n 3 $f; done
-python3 scripts/bench_frontend.py > $O/bench_frontend.txt 2>&1; tail -n 2 $O/bench_frontend.txt
+bash scripts/pmc_attn.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc.txt $O/attn_pmc.txt 2>/dev/null; head -n 12 $O/attn_pmc.txt   # (profiles/${R}_attn_pmc.txt)
+python3 scripts/bench_frontend.py > $O/bench_frontend.txt 2>&1; tail -n 8 $O/bench_frontend.txt
 bash scripts/pmc_frontend.sh $O/pmc_fe > $O/frontend_pmc.txt 2>&1; rm -rf $O/pmc_fe; head -n 3 $O/frontend_pmc.txt     # (profiles/${R}_frontend_pmc.txt = this + a reading)
 # BASELINE config 3's global batch on ONE GPU (strong-scaling anchor, ~200 GB resident), and the headline through the self-launch path
 python3 bench.py --global_batch 1024 --steps 5 --warmup 2 --no_cpu_baseline > $O/bench_vit_base_bt_10s_b1024_line.json 2> $O/bench_b1024.err || echo "b1024 failed"

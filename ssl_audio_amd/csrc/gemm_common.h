@@ -213,15 +213,15 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x4&
 // tail is ISSUE-bound (cdna_hip_programming.md T21).  Staging the tile through 9 KiB of this wave's LDS turns it
 // into 8 x 16-byte stores per lane that write whole 128-byte row segments.  fp32 outputs already store 16 B per lane.
 constexpr int EPI_STRIDE = 144;                 // bytes per staged row: 64 bf16 + 16 B pad (16-byte aligned rows)
-// XOR key of the swizzled (128-byte row) scratch.  The row-per-lane side moves 8 bytes per lane (ds_write_b64 / ds_read_b64: 32 lanes per
-// LDS cycle = rows c = 0..15 x two lanes): two rows of equal parity share their 32 banks, so the 8 rows of one parity must get 8
-// DIFFERENT chunk positions.  (row >> 1) & 7 does that; the key of rounds 1-4, row & 7, gave rows c and c + 8 the same position -- a
-// 2-way conflict on every such access, 12 % of the persistent kernel's LDS-active cycles (profiles/r04_gemm_pmc.txt; VERDICT r4 #4a).
-// The 16-byte side (16 lanes per cycle = two whole rows) is conflict-free under any key.
-#ifndef SA_EPI_KEY_OLD
-#define SA_EPI_KEY_OLD 0                      // (A/B builds only: scripts/ab_build.sh)
-#endif
-__device__ __forceinline__ int epi_key(int row) { return SA_EPI_KEY_OLD ? (row & 7) : ((row >> 1) & 7); }
+// XOR key of the swizzled (128-byte row) scratch.  Its row-per-lane side (ds_write_b64 / ds_read_b64 of 8 bytes per lane) is a 2-way bank
+// conflict by construction, whatever the key: a ds_write_b64 is serviced in groups of 16 consecutive lanes with 32 banks of 4 bytes
+// (MI355X_MICROARCH.md, LDS table) -- here 16 ROWS at one 8-byte column piece, and rows 128 bytes apart share their banks, so 16 pieces
+// need 16 distinct 8-byte slots of a 128-byte window, but a chunk XOR leaves the piece's half (g & 1) fixed: 8 slots.  Spreading them
+// over 16 slots means swapping the two halves of a 16-byte chunk for half of the rows, which the 16-byte read side would have to undo
+// with 4 v_cndmask per read -- in an epilogue that is VALU-bound.  Round 5 measured the conflicts as free: a key that removes the
+// conflict under 64-bank, 32-lane servicing ((row >> 1) & 7) left both SQ_LDS_BANK_CONFLICT (3.825e6 per launch set) and the block
+// time (2.794 / 2.812 vs 2.808 / 2.797 ms) where they were (VERDICT r4 #4a).
+__device__ __forceinline__ int epi_key(int row) { return row & 7; }
 constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
 
 // SWZ = false: padded rows (144 B, 9 KiB per wave).  SWZ = true: 128-byte rows with the 16-byte chunk XOR-ed by epi_key(row),
