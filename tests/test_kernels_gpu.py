@@ -415,6 +415,27 @@ def test_logmel_per_clip_start_length_offset(dev):
         mel(wave.to(dev), crop_frames=T, start=starts[:3])
 
 
+def test_logmel_per_clip_out_of_range_values_are_clamped(dev):
+    """The per-clip vectors come from the caller's sampler: values that would reach outside a clip's row must not turn into out-of-range
+    reads (the kernel clamps; include/ssl_audio_hip.h).  Zero or too-short lengths, an offset at / past the row's end and a start past
+    the clip's last frame give the normalised zero pad; a negative start or offset counts as 0; a length longer than the row is cut to it."""
+    from oracle import frontend as ofe
+    T, n = 40, 16000
+    wave = synth_wave(7, n, 53)
+    pad = np.float32((0.0 + 0.8294) / 4.6230)
+    starts = [0, 0, 0, 10 ** 6, -5, 0, 3]
+    lens = [0, 512, n, n, n, 10 ** 7, n]
+    offs = [0, 0, n, 0, -9, 0, n - 700]
+    out = fe.MelSpectrogram()(wave.to(dev), crop_frames=T, start=starts, lengths=lens, offsets=offs, norm_stats=(-0.8294, 4.6230)).cpu().numpy()[:, 0]
+    for b in (0, 1, 2, 3):
+        assert np.all(out[b] == pad), b
+    full = ofe.crop_pad_normalize(ofe.logmel(wave.numpy()), T, 0, -0.8294, 4.6230)
+    assert np.abs(out[4] - full[4]).max() < 2e-3 and np.abs(out[5] - full[5]).max() < 2e-3
+    tail = ofe.logmel(wave[6, n - 700:].numpy())                                   # 700 samples: 5 frames, 3 skipped -> 2 live frames, then pad
+    assert np.abs(out[6][:, :2] - (tail[:, 3:5] + 0.8294) / 4.6230).max() < 2e-3 and np.all(out[6][:, 2:] == pad)
+    assert np.isfinite(out).all()
+
+
 def test_logmel_padding_groups_do_no_transform_work(dev):
     """Clips shorter than the crop: the 16-frame groups that lie wholly in the padding are written without FFT / MFMA work, so a batch
     of 1 s clips padded to 1001 frames costs about a tenth of a batch of 10 s clips (and equals the oracle's right zero pad)."""
