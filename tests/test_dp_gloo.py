@@ -193,7 +193,7 @@ def _worker_body(rank, world, port, q):
 
 def _bf16_gradient_buckets(rank, world, cpu_ops):
     """GradSync(grad_dtype="bf16") (VERDICT r4 #2 iii): a range is cast to bf16, SUM all-reduced at half the bytes and widened back into
-    the fp32 gradient buffer.  Against the fp32 mode on the same gradients: relative L2 error <= 3e-3 (two bf16 roundings -- each rank's
+    the fp32 gradient buffer.  Against the fp32 mode on the same gradients: relative L2 error <= 2e-3 sqrt(W) (at two ranks: two bf16 roundings -- each rank's
     share, then the sum -- of unit roundoff 2^-9 each: 2.3e-3 measured on these gradients; VERDICT asked 2e-3, which one rounding meets and two
     do not), every element within 2^-7 of the fp32 sum's magnitude scale, what no range covers untouched, and exactly equal
     where the values are bf16-representable."""
@@ -221,7 +221,10 @@ def _bf16_gradient_buckets(rank, world, cpu_ops):
     ref = run("fp32", local)
     got = run("bf16", local)
     rel = float((got - ref).norm() / ref.norm())
-    ok = rel < 3e-3 and bool(torch.all((got - ref).abs() <= 2.0 ** -7 * (ref.abs() + local.abs())))
+    abs_sum = local.abs().clone()
+    dist.all_reduce(abs_sum)                                   # sum over ranks of |share|: the scale every rounding of the bf16 sum is relative to
+    # W shares are rounded, then W - 1 partial sums: the error grows like sqrt(W) (2.3e-3 at two ranks, 3.0e-3 at four on these gradients)
+    ok = rel < 2e-3 * world ** 0.5 and bool(torch.all((got - ref).abs() <= world * 2.0 ** -8 * abs_sum))   # (W roundings of at most one bf16 ulp of the running scale)
     exact = torch.full((4096,), 0.75 * (rank + 1))              # bf16-representable shares and sum: the two modes agree exactly
     ok = ok and torch.equal(run("bf16", exact), run("fp32", exact))
     try:
@@ -277,8 +280,10 @@ def _close(a, b, tol):
     return float((a - b).norm() / (b.norm() + 1e-30)) <= tol
 
 
-def test_two_rank_protocol():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_protocol(world):
+    """world = 4: the same checks with four gloo ranks of 4 rows each (more ranks than the 2 a one-GPU box can hold on its card: the
+    all-gather / all-reduce packing, Chan's merge over W > 2 partial statistics, the bucket launch order, bf16 gradient buckets)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -299,13 +304,15 @@ def test_two_rank_protocol():
     _patch_cpu_ops()
     x1g, x2g = _global_inputs()
     ref = _dropin_step(x1g, x2g, wrap=False)
-    r0, r1 = res[0][4], res[1][4]
-    assert abs(r0["loss"] - r1["loss"]) <= 1e-6 * abs(ref["loss"])             # every rank holds the GLOBAL loss
+    r0 = res[0][4]
+    for rr in range(1, world):
+        assert abs(r0["loss"] - res[rr][4]["loss"]) <= 1e-6 * abs(ref["loss"])     # every rank holds the GLOBAL loss
     assert abs(r0["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (r0["loss"], ref["loss"])
     for k in [k for k in ref if k.startswith("g.")]:
-        assert np.array_equal(r0[k], r1[k]), k                                    # all-reduced: bit-identical replicas
+        for rr in range(1, world):
+            assert np.array_equal(r0[k], res[rr][4][k]), k                            # all-reduced: bit-identical replicas
         assert _close(r0[k], ref[k], 2e-3), k                                     # SUM over ranks == single-process gradient
-    assert _close(np.concatenate([r0["dx1"], r1["dx1"]]), ref["dx1"], 2e-3)            # input gradients: each rank its own rows
+    assert _close(np.concatenate([res[rr][4]["dx1"] for rr in range(world)]), ref["dx1"], 2e-3)   # input gradients: each rank its own rows
     for k in ("head.running_mean", "head.running_var", "crit.running_mean", "crit.running_var"):
         assert _close(r0[k], ref[k], 1e-4), k                                     # SyncBN / loss-BN buffers == global-batch statistics
     assert r0["crit.nbt"] == ref["crit.nbt"] == 2
@@ -319,8 +326,9 @@ def test_two_rank_protocol():
 
     # ---- literal_ddp == the reference under DDP: per-rank loss BN, c / B_local, SUM all-reduce.  The projector's
     # BN stays synchronised (the reference converts it to SyncBN, utils/utils.py:411), so z is the global-statistics z.
-    lit0, lit1 = res[0][5], res[1][5]
-    assert abs(lit0["loss"] - lit1["loss"]) <= 1e-6 * abs(lit0["loss"])
+    lit0 = res[0][5]
+    for rr in range(1, world):
+        assert abs(lit0["loss"] - res[rr][5]["loss"]) <= 1e-6 * abs(lit0["loss"])
     parts = []
     zg = z.detach()
     z1g, z2g = zg.chunk(2)
