@@ -396,11 +396,16 @@ def main():
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             nb = sum(r[2] for r in recs)
             fl = sum(r[3] for r in recs)
+            mfl = sum(r[4] for r in recs)
             if ms > 0:
                 gbs = nb / (ms * 1e-3) / 1e9
                 hbm_kernels[kname] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                       "launches": len(recs), "avg_launch_us": round(ms * 1e3 / len(recs), 2),
                                       "algorithmic_bytes_per_launch": round(nb / len(recs)), "share_of_step": round((ms / psteps) / (dt / args.steps * 1e3), 4)}
+                if mfl > 0:    # the attention kernels: bf16 MFMA work next to their bytes (they sit under BOTH roofs: DESIGN.md section 6)
+                    tf = mfl / (ms * 1e-3) / 1e12
+                    hbm_kernels[kname]["mfma"] = {"achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                                                  "algorithmic_flop_per_launch": round(mfl / len(recs))}
                 if fl > 0:     # arithmetic outweighs bytes (the FFT frontend: 87 flop per byte): the fp32 vector rate is the nearer bound
                     tf = fl / (ms * 1e-3) / 1e12
                     hbm_kernels[kname]["nearer_bound"] = {"bound": "valu_f32", "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",

@@ -584,7 +584,7 @@ int launch256_persist(GemmParams p, hipStream_t stream) {
     SA_LAUNCH_CHECK("sa_gemm_bf16(256 persistent, compact epilogue)");                                                     \
     return 0;                                                                                                              \
   }
-    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(5) SA_EPI_CASE(6) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
+    switch (p.epi_kind) { SA_EPI_CASE(1) SA_EPI_CASE(3) SA_EPI_CASE(5) SA_EPI_CASE(6) SA_EPI_CASE(8) default: break; }   // kind 2 (separate erf-GELU pass) spills: general path
 #undef SA_EPI_CASE
   }
   hipLaunchKernelGGL((gemm256_persist_kernel<A_KM, B_KM>), grid, dim3(512), PERSIST_LDS, stream, p);
@@ -1173,6 +1173,7 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     if (base_ok && bf16_only && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out) p.epi_kind = 1;
     else if (base_ok && bf16_only && a->act == 1 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 2;   // (not dispatched: spills)
     else if (base_ok && bf16_only && a->act == 3 && a->aux_out && a->ldaux % 8 == 0 && !a->colsum_out) p.epi_kind = 6;
+    else if (base_ok && bf16_only && a->act == 1 && !a->aux_out && !a->aux_in && !a->colsum_out) p.epi_kind = 8;   // GELU only (no backward to come)
     else if (base_ok && a->out_f32 && !a->out_bf16 && a->residual && a->act == 0 && !a->aux_in && !a->aux_out && !a->colsum_out &&
              a->ldr % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->residual | (uintptr_t)a->out_f32) & 15) == 0) p.epi_kind = 3;
     else if (base_ok && bf16_only && (a->act == 2 || a->act == 4) && a->aux_in && !a->bias && a->ldaux % 8 == 0 && ((uintptr_t)a->aux_in & 15) == 0)

@@ -229,7 +229,7 @@ constexpr int EPI_BYTES = 64 * EPI_STRIDE;      // 9216 B per wave
 // stage it has just finished reading while the other stage already receives the next tile).
 // NI = 16-row groups handled per call: 4 (a 64-row block, 8 KiB of scratch) or 2 (32 rows, 4 KiB: the phased kernel, whose
 // pipeline owns 128 of the 160 KiB of LDS).
-template <bool SWZ, int XF = 0, int NI = 4>   // XF = 1: store GELU'(v) and REPLACE v by GELU(v) (forward fc1 with act = 3; one exp + one rcp for both)
+template <bool SWZ, int XF = 0, int NI = 4>   // XF = 1: store GELU'(v) and REPLACE v by GELU(v) (forward fc1 with act = 3; one exp + one rcp for both); XF = 2: store GELU(v)
 __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v)[NI][4], char* wlds, bf16_t* dst, int64_t ld,
                                                   int m_base, int n_base, bool remap, int lane) {
   const int g = lane >> 4, c = lane & 15;
@@ -247,6 +247,14 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
           v[i][j][r] = y;
         }
         h = bf16x4{f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
+      } else if constexpr (XF == 2) {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float dy;
+          gelu_pair(v[i][j][r], y[r], dy);                  // (the derivative's two extra operations are dead code here)
+        }
+        h = bf16x4{f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
       }
       const int row = i * 16 + c;
       if constexpr (SWZ)
@@ -331,6 +339,8 @@ __device__ __forceinline__ void staged_load_bf16(const GemmParams& p, char* wlds
 //   kind 4: alpha * acc * GELU'(aux_in) -> bf16 (+ column sums)          (fc2 dgrad, act 2: aux holds the pre-activation)
 //   kind 5: alpha * acc * aux_in -> bf16 (+ column sums)                 (fc2 dgrad, act 4: aux already holds GELU')
 //   kind 6: alpha * acc + bias -> aux_out = GELU'(.), bf16 = GELU(.)     (fc1 forward, act 3)
+//   kind 8: alpha * acc + bias -> bf16 = GELU(.)                          (fc1 forward WITHOUT a backward to come: act 1, no aux -- the
+//           EMA target network of main_bt_byol.py:97-101, encode_vit / the HEAR wrappers; until round 5 the general epilogue)
 // NI / CSM: see staged_store_bf16; with NI = 2 a 64-row block is two calls and the fused column sums travel between them in
 // `csacc` (CSM 1: first half, keep the sums; CSM 2: second half, add and write the workspace row; CSM 0: whole block at once).
 template <bool SWZ, int kind, int NI = 4, int CSM = 0>
@@ -356,6 +366,8 @@ __device__ __forceinline__ void wave_epilogue_compact(const GemmParams& p, f32x4
   }
   if constexpr (kind == 1) {
     staged_store_bf16<SWZ, 0, NI>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
+  } else if constexpr (kind == 8) {
+    staged_store_bf16<SWZ, 2, NI>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);
   } else if constexpr (kind == 6) {          // fc1 forward, act 3: aux <- GELU'(v), acc <- GELU(v) in one pass, then the activation
     staged_store_bf16<SWZ, 1, NI>(p, acc, wlds, p.aux_out, p.ldaux, m_base, n_base, false, lane);
     staged_store_bf16<SWZ, 0, NI>(p, acc, wlds, p.out_bf16, p.ldo_bf16, m_base, n_base, false, lane);

@@ -22,9 +22,10 @@ GEMM_PROFILE = None   # set to a list by bench.py to collect (start event, end e
 STREAM_PROFILE = None  # set to a dict by bench.py: kernel name -> [(start event, end event, algorithmic bytes)] for the HBM-bound front kernels
 
 
-def _timed(name, nbytes, launch, flops=0.0):
+def _timed(name, nbytes, launch, flops=0.0, mfma_flops=0.0):
     """bench.py's roofline leg for the HBM-bound kernels: HIP events on the launch stream around one launch
-    (flops: fp32 vector work of the launch, for a kernel whose arithmetic outweighs its bytes)."""
+    (flops: fp32 vector work of the launch, for a kernel whose arithmetic outweighs its bytes; mfma_flops: bf16 matrix work, for the
+    attention kernels, which the bench line prices against both roofs)."""
     if STREAM_PROFILE is None:
         launch()
         return
@@ -32,7 +33,7 @@ def _timed(name, nbytes, launch, flops=0.0):
     e0.record()
     launch()
     e1.record()
-    STREAM_PROFILE.setdefault(name, []).append((e0, e1, float(nbytes), float(flops)))
+    STREAM_PROFILE.setdefault(name, []).append((e0, e1, float(nbytes), float(flops), float(mfma_flops)))
 
 
 def _stream():
@@ -123,6 +124,8 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
         epi = 1
     elif plain and bf16_only and act == 3 and aux_out is not None and colsum_out is None:
         epi = 6
+    elif plain and bf16_only and act == 1 and aux_out is None and aux_in is None and colsum_out is None:
+        epi = 8
     elif plain and epi3:
         epi = 3
     elif plain and bf16_only and act in (2, 4) and aux_in is not None and bias is None:
@@ -288,8 +291,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dx_f32=None, dx_bf16=N
 def attention_fwd(qkv, H, N, scale, out, lse=None, n_query=0):
     rows, w, ld = _rows(_req(qkv, BF16, "qkv"), "qkv")
     Cdim = w // 3
-    check(lib().sa_attention_fwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(_req(out, BF16, "out")),
-                                 _rows(out, "out")[2], _p(lse), _stream()), "sa_attention_fwd")
+    nq = N if not n_query or n_query > N else int(n_query)
+    # algorithmic bytes: q (the queried rows), k, v read once, the output rows written once (+ lse); MFMA flops 4 nq N 64 per (sequence, head)
+    _timed("attn_fwd_kernel", (rows // N) * (2.0 * Cdim * (2 * N + 2 * nq) + 4.0 * H * nq), lambda: check(
+        lib().sa_attention_fwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(_req(out, BF16, "out")),
+                               _rows(out, "out")[2], _p(lse), _stream()), "sa_attention_fwd"), mfma_flops=4.0 * (rows // N) * H * nq * N * 64)
 
 
 def attention_bwd(qkv, H, N, scale, out, dout, lse, dqkv, n_query=0):
@@ -297,8 +303,12 @@ def attention_bwd(qkv, H, N, scale, out, dout, lse, dqkv, n_query=0):
     Cdim = w // 3
     if _rows(dqkv, "dqkv")[2] != ld or _rows(dout, "dout")[2] != _rows(out, "out")[2]:
         raise ValueError("attention_bwd: dqkv/qkv and dout/out must share leading dimensions")
-    check(lib().sa_attention_bwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(out), _p(_req(dout, BF16, "dout")), _rows(out, "out")[2],
-                                 _p(_req(lse, F32, "lse")), _p(_req(dqkv, BF16, "dqkv")), _stream()), "sa_attention_bwd")
+    nq = N if not n_query or n_query > N else int(n_query)
+    # algorithmic bytes: qkv, out, dout read once, dqkv written once; MFMA flops 2.5 x the forward's (two passes recompute S and dP)
+    _timed("attn_bwd_kernel", (rows // N) * 2.0 * Cdim * (3 * N + 2 * nq + 3 * N), lambda: check(
+        lib().sa_attention_bwd(_p(qkv), rows, ld, Cdim, H, N, int(n_query), float(scale), _p(out), _p(_req(dout, BF16, "dout")), _rows(out, "out")[2],
+                               _p(_req(lse, F32, "lse")), _p(_req(dqkv, BF16, "dqkv")), _stream()), "sa_attention_bwd"),
+           mfma_flops=10.0 * (rows // N) * H * nq * N * 64)
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm pieces

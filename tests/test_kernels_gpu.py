@@ -155,6 +155,22 @@ def test_gemm_tile_modes(dev, env):
     assert r.returncode == 0 and "ok tile=" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_gemm_gelu_only_compact_epilogue(dev):
+    """fc1 forward WITHOUT a backward to come (act = 1, no aux: the EMA target network of main_bt_byol.py:97-101, encode_vit, the HEAR
+    wrappers): on the persistent 256 x 256 kernel it takes the compact GELU-only epilogue (kind 8; until round 5 the general one).
+    Exact-erf GELU against torch (bf16 output), ragged last row tile, and equal to the GELU half of the act = 3 launch bit for bit."""
+    M, N, K = 33000, 768, 256
+    A = bf(rnd((M, K), 61)); W = bf(rnd((N, K), 62, 0.1)); bias = rnd((N,), 63)
+    ref = torch.nn.functional.gelu(A.double() @ W.double().t() + bias.double())
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=1, out_bf16=out)
+    assert rel_err(out, ref) < 4e-3
+    assert float((out.double().cpu() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
+    out3, dg = torch.empty_like(out), torch.empty_like(out)
+    ops.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=3, aux_out=dg, out_bf16=out3)
+    assert torch.equal(out, out3)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (4000, 2112, 256)])
 def test_gemm_fused_column_sums(dev, M, N, K):
     """colsum_out += column sums of the fp32 epilogue result (fc1's bias gradient taken in the fc2-dgrad epilogue), small
