@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 249
+FWD = len(sys.argv) > 4 and sys.argv[4] == "fwd"          # the forward kernel's timeline instead (stamps 0 entry, 1 loads issued, 2 landed, 5 done, 6 drained)
 C = 64 * H
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = (torch.randn(S * N, 3 * C, device=dev, generator=g)).to(torch.bfloat16)
@@ -22,14 +23,15 @@ dqkv = torch.empty_like(qkv)
 h = _lib.lib()
 buf = torch.zeros(S * H * 2 * 8, dtype=torch.int64, device=dev)
 h.sa_attn_dbg_set.argtypes = [ctypes.c_void_p]; h.sa_attn_dbg_set.restype = ctypes.c_int
+run = (lambda: ops.attention_fwd(qkv, H, N, 0.125, out, lse)) if FWD else (lambda: ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv))
 for _ in range(3):
-    ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv)
+    run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv); e1.record(); torch.cuda.synchronize()
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
 t_plain = e0.elapsed_time(e1) * 1e3
 assert h.sa_attn_dbg_set(ctypes.c_void_p(buf.data_ptr())) == 0
-e0.record(); ops.attention_bwd(qkv, H, N, 0.125, out, dout, lse, dqkv); e1.record(); torch.cuda.synchronize()
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
 t_stamped = e0.elapsed_time(e1) * 1e3
 h.sa_attn_dbg_set(ctypes.c_void_p(0))
 st = buf.cpu().numpy().astype(np.uint64).reshape(S * H, 2, 8)
@@ -37,7 +39,7 @@ hw = st[:, 0, 7]
 xcc, se, sh, cu = (hw >> np.uint64(32)) & np.uint64(15), (hw >> np.uint64(13)) & np.uint64(7), (hw >> np.uint64(12)) & np.uint64(1), (hw >> np.uint64(8)) & np.uint64(15)
 cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 t = st[:, :, :7].astype(np.int64)
-print(f"attention backward S={S} H={H} N={N}: {t_plain:.1f} us ({t_stamped:.1f} us with stamps); {len(np.unique(cuid))} distinct CUs host {S * H} workgroups")
+print(f"attention {'forward' if FWD else 'backward'} S={S} H={H} N={N}: {t_plain:.1f} us ({t_stamped:.1f} us with stamps); {len(np.unique(cuid))} distinct CUs host {S * H} workgroups")
 names = ["issue loads", "loads land (wait + barrier)", "pass A (dQ)", "hand-over", "pass B (dK, dV)", "store drain"]
 d = np.diff(t[:, 0, :], axis=1).astype(np.float64)
 life = (t[:, 0, 6] - t[:, 0, 0]).astype(np.float64)

@@ -139,12 +139,18 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
       q[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
     }
   };
+#if SA_ATTN_DBG
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  ATTN_STAMP(0)
   bf16x8 qf[2];
   if (wave < nqt) load_q(wave, qf);
   stage_rows(rs, Kimg, ld, C + h * HD, nks * 32, wave, lane, NW_FWD);
   stage_rows(rs, Vimg, ld, 2 * C + h * HD, nks * 32, wave, lane, NW_FWD);
+  ATTN_STAMP(1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  ATTN_STAMP(2)
 
   // accumulator start of the last key tile: -inf on keys >= N, else 0 -- rebuilt per query tile from ONE live register (the lane's
   // first padded element; four live registers here were spilled in the FULL instantiation, which runs at the 128-register cap)
@@ -211,6 +217,22 @@ __global__ __launch_bounds__(64 * NW_FWD, NMAX == 256 ? 4 : 2) void attn_fwd_ker
       if (g == 0 && lse) lse[((int64_t)s * H + h) * N + query] = mx * scale + __logf(sum);
     }
   }
+  // (One workgroup per head, NOT a persistent walk: the forward's per-CU timeline -- scripts/diag/attn_timeline.py ... fwd,
+  // profiles/r05_attn_timeline.txt -- shows 1.57 workgroups resident on average, a slot empty ~6.5 k cycles of a 29 k-cycle period; a
+  // two-per-CU grid walking the heads with a barrier per head measured 107 us against 98 - 99 us for this form: the walk's workgroups
+  // load and compute in lock-step per CU.)
+#if SA_ATTN_DBG
+  ATTN_STAMP(5)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(6)
+  dbg_t[3] = dbg_t[4] = dbg_t[2];        // (no passes A / B here: the timeline script's columns 2 .. 5 are one compute phase)
+  if (sa_attn_dbg_ptr && lane == 0 && (wave == 0 || wave == NW_FWD - 1)) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    unsigned long long* o_ = sa_attn_dbg_ptr + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+    for (int k = 0; k < 7; ++k) o_[k] = dbg_t[k];
+    o_[7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 // =====================================================================================================
