@@ -301,7 +301,7 @@ def main():
     note(f"model + {2 * B} synthetic clips resident; warm-up x{args.warmup}")
     # (measured: vit_base 42.7 ms eager vs 43.3 ms replayed, vit_tiny 18.11 vs 18.13 -- every workload here is GPU-bound, so eager
     # is the default and --graph the option)
-    use_graph = args.graph and not args.no_graph and mode != "mae"
+    use_graph = args.graph and not args.no_graph           # (round 5: the masked MAE step is capturable too: fixed mask ratio)
     for i in range(max(args.warmup, 1)):
         trainer.step(pool[i % 2])
         torch.cuda.synchronize()

@@ -168,7 +168,10 @@ class MaskedAutoencoderViT(nn.Module):
             return self._learned_pos(freq_bins, frames)[0]
         key = (freq_bins, frames, self.pos_embed.device, self.pos_embed._version)
         if key not in self._pos_cache:
-            self._pos_cache.clear()
+            # keep one table per input WIDTH (a step with local crops alternates between two: clearing on every miss rebuilt both on the host
+            # every step, and made such a step uncapturable); drop only what a rewritten / moved pos_embed made stale
+            for k in [k for k in self._pos_cache if k[0] != "A" and k[2:] != key[2:]]:
+                del self._pos_cache[k]
             pos = interpolate_pos_encoding(self.pos_embed.detach().cpu().numpy(), self.grid_size(), freq_bins, frames,
                                            self.patch_size())
             self._pos_cache[key] = torch.from_numpy(pos).float().to(self.pos_embed.device).contiguous()

@@ -395,6 +395,7 @@ class BarlowTwinsTrainer:
         if mode == "byol":
             self.param_groups += [{"lr": cfg.lr, "weight_decay": cfg.wd}, {"lr": cfg.lr, "weight_decay": 0.0}]
         self._graph = self._graph_views = self._graph_loss = None
+        self._graph_mask_ratio = None                    # the mask ratio a captured step was recorded with (None: unmasked)
         self.use_graph = True                            # False: run eagerly although a graph exists (profiling passes with per-launch events)
         self.mask_ratio_schedule = None                  # per-iteration table (utils.sine_scheduler_increase, main.py:442), or None
         self.last_loss = None
@@ -494,7 +495,11 @@ class BarlowTwinsTrainer:
         self.flat.stage_hyper(g[0]["lr"], lr_nodecay=g[1]["lr"])
         if self.mode == "byol":
             self.flat_pred.stage_hyper(g[2]["lr"], lr_nodecay=g[3]["lr"])
-        if self._graph is not None and self.use_graph and mask_ratio is None and not getattr(self.cfg, "mask", False):
+        if self._graph is not None and self.use_graph:
+            # the captured step holds ITS mask ratio (the token counts are baked into its launches): another ratio cannot be replayed
+            if mask_ratio is not None and self._graph_mask_ratio is not None and float(mask_ratio) != float(self._graph_mask_ratio):
+                raise RuntimeError(f"the captured step masks {self._graph_mask_ratio} of the tokens; a step at mask_ratio {mask_ratio} needs use_graph = False "
+                                   "(per-iteration mask-ratio schedules change the launches' shapes)")
             for dst, src in zip(self._graph_views, views):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
@@ -573,16 +578,26 @@ class BarlowTwinsTrainer:
             return
         if self._steps < 1:
             raise RuntimeError("enable_graph(): run at least one eager step first (workspaces and weight copies are allocated lazily)")
-        if self.mode == "mae" or getattr(self.cfg, "mask", False) or getattr(self.cfg, "masked_recon", False):
-            raise NotImplementedError("graph capture with random masking is not supported: the masking indices come from torch's generator "
-                                      "and a host-side argsort per step")
-        if self.L:
-            raise NotImplementedError("graph capture with local crops is not supported (the static input buffers hold the two global views)")
+        masked = self.mode == "mae" or bool(getattr(self.cfg, "mask", False))
+        if masked and (getattr(self.cfg, "random_mask_ratio", False) or self.mask_ratio_schedule is not None):
+            raise NotImplementedError("graph capture with a mask ratio that changes from step to step (random_mask_ratio / a schedule table): the number "
+                                      "of kept tokens is baked into the captured launches")
+        # Random masking itself is capturable: the indices are device-side index bookkeeping (torch.rand from the device generator, whose
+        # Philox offset a replay advances like an eager step, argsort, gather -- models/mae.py:332-339) and every token movement they drive
+        # is a sa_* launch; with a fixed ratio all shapes are static.
+        self._graph_mask_ratio = float(self.cfg.mask_ratio) if masked else None
         pair = torch.empty(2, self.B, 1, self.cfg.n_mels, self.cfg.crop_frames, device=self.device)
         if views is not None:
             pair[0].copy_(views[0]); pair[1].copy_(views[1])
         self._graph_pair = pair
         self._graph_views = [pair[0], pair[1]]
+        if self.L:                                           # static buffers for the L local crops too (utils/transforms.py:38-47)
+            lh, lw = tuple(self.cfg.local_crops_size)
+            loc = torch.empty(self.L, self.B, 1, lh, lw, device=self.device)
+            if views is not None:
+                for l in range(self.L):
+                    loc[l].copy_(views[2 + l])
+            self._graph_views += [loc[l] for l in range(self.L)]
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
