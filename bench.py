@@ -43,7 +43,7 @@ def source_sha():
     at and is ignored when stale."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_bf16.hip", "gemm_phase.hip", "gemm_common.h", "common.h"):
+    for f in ("gemm_bf16.hip", "gemm_phase.hip", "gemm_stream.hip", "gemm_common.h", "common.h"):
         h.update(open(os.path.join(ROOT, "ssl_audio_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -57,7 +57,8 @@ typedef struct SaGemmArgs {
   int32_t split_k;              /* >= 1.  > 1: K is split over workgroups and partial tiles are atomically
                                    ADDED into out_f32 (caller zeroes / owns accumulation); only alpha is applied */
   int32_t accumulate;           /* split_k == 1 only: out_f32 += v instead of = v */
-  int32_t tile256;              /* split_k > 1 only: use the 256 x 256 tile (one workgroup per CU) instead of 128 x 128 */
+  int32_t tile256;              /* split_k > 1 only: 1 = the 256 x 256 tile (one workgroup per CU) instead of 128 x 128; 2 = the 192 x 192
+                                   streaming kernel (both operands k-strided; three K-steps in LDS, for outputs a few hundred wide) */
   float* colsum_out;            /* optional [N]: += column sums of the fp32 epilogue result (the bias gradient of the Linear that
                                    produced this GEMM's A operand's gradient, e.g. fc1's bias from the fc2 dgrad: utils of
                                    models/mae.py:155 backward).  Needs split_k == 1, N % 64 == 0 and colsum_ws. */

@@ -5,7 +5,7 @@ block's forward + backward makes, exactly as engine.block_forward / block_backwa
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ssl_audio_amd import ops
+from ssl_audio_amd import ops, engine
 dev = torch.device("cuda:0")
 d = int(os.environ.get("SA_BENCH_D", "768"))
 M = int(os.environ.get("SA_BENCH_SEQS", "256")) * 249
@@ -36,9 +36,13 @@ cases = [
 for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16), ("fc1", 4 * d, d, h4, x16), ("fc2", d, 4 * d, x16, h4)]:
     out = torch.zeros(N, K, device=dev)
     use256 = ((N + 255) // 256) * ((K + 255) // 256) >= int(os.environ.get("SA_WGRAD256_MIN", "9"))
-    sk = ops.pick_split_k(N, K, M, tile=256) if use256 else ops.pick_split_k(N, K, M)
-    cases.append((f"wgrad TN {name} split{sk}{' 256' if use256 else ''}",
-                  lambda out=out, dy=dy, xx=xx, sk=sk, use256=use256: ops.gemm(dy, xx, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=sk, tile256=use256), 2.0 * M * N * K))
+    if engine.stream_wgrad(N, K, M) or os.environ.get("SA_BENCH_STREAM") == "1":
+        use256 = 2
+    sk = ops.pick_split_k(N, K, M, tile={0: 128, 1: 256, 2: 192}[int(use256)])
+    if os.environ.get("SA_BENCH_SPLIT"):
+        sk = int(os.environ["SA_BENCH_SPLIT"])
+    cases.append((f"wgrad TN {name} split{sk}{['', ' 256', ' 192 stream'][int(use256)]}",
+                  lambda out=out, dy=dy, xx=xx, sk=sk, use256=use256: ops.gemm(dy, xx, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=sk, tile256=int(use256)), 2.0 * M * N * K))
 only = sys.argv[1] if len(sys.argv) > 1 else None
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tot_t = tot_f = 0.0

@@ -1238,6 +1238,11 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
     if (!a->a_kmajor && a->b_kmajor) return launch256_persist<false, true>(p, stream);
     return launch256_persist<false, false>(p, stream);
   }
+  if (a->split_k > 1 && a->tile256 == 2) {
+    SA_CHECK_ARG(!a->a_kmajor && !a->b_kmajor, "sa_gemm_bf16: tile256 = 2 (the 192 x 192 streaming kernel) takes k-strided operands only");
+    SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 192 tile");
+    return sagemm::launch_stream(p, stream);
+  }
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     static const char* wphase = getenv("SA_GEMM_WGRAD_PHASE");

@@ -1,5 +1,5 @@
 // Shared pieces of the bf16 MFMA GEMM translation units (gemm_bf16.hip: dispatch + the general kernels; gemm_phase.hip: the
-// phased persistent 256 x 256 kernel): problem description, operand staging, fragment reads and the fused epilogues.
+// phased persistent 256 x 256 kernel; gemm_stream.hip: the 192 x 192 streaming split-K kernel): problem description, operand staging, fragment reads and the fused epilogues.
 #pragma once
 #include <stdlib.h>
 #include <type_traits>
@@ -50,6 +50,8 @@ int* next_tile_counter(hipStream_t stream);
 // gemm_phase.hip: launches the phased kernel for (layout, split) if it covers the problem (compact epilogue kinds 1/3/5/6 or split-K
 // atomics); returns -1 when it does not, 0 on success, 2 on a launch error
 int launch_phase(GemmParams p, bool a_kmajor, bool b_kmajor, bool split, hipStream_t stream);
+// gemm_stream.hip: the 192 x 192 streaming split-K kernel (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error
+int launch_stream(GemmParams p, hipStream_t stream);
 }  // namespace sagemm
 using sagemm::GemmParams;
 using sagemm::budget_slots;

@@ -1,0 +1,172 @@
+// Streaming split-K TN kernel for NARROW weight gradients (dW[N_out, K_out] = dY^T X with both extents a few hundred wide and the
+// reduction a hundred thousand rows long: ViT-T, d = 192).  Own translation unit like gemm_phase.hip.
+#include "gemm_common.h"
+
+namespace {
+
+// =====================================================================================================
+// What bounds these launches: 2 * M * N * K flop over (M + N) * K * 2 bytes is 144 - 190 flop/B at N, M in {192, 576, 768} -- under the
+// 312 flop/B ridge, so the operand rows should stream from HBM ONCE at the HBM rate and the matrix pipe idles three quarters of the time.
+// The 128 x 128 kernel (two 4-wave workgroups per CU, one stage ahead, `vmcnt(0)` + barrier per K-step) moves 2.7 x the algorithmic
+// bytes through L2 -> LDS (a 576 x 192 output is 5 x 2 tiles: dY is fetched twice, X five times) in bursts, and runs at 3.9 - 4.0 TB/s
+// of algorithmic bytes; the 256 x 256 split-K kernel pads 192 to 256 and is no faster (scripts/bench_gemm.py, SA_BENCH_D=192).
+//
+// This kernel: a 192 x 192 output tile per workgroup (d = 192 outputs are 3 x 1, 1 x 1, 4 x 1, 1 x 4 tiles: no padding, the narrow
+// operand is fetched by at most four workgroups that run side by side on one XCD), one 8-wave workgroup per CU, and a THREE-stage
+// ring of K-steps in LDS: 48 KiB per stage (2 operands x three 8 KiB images of 64 k-rows x 64 columns), two stages = 96 KiB per CU
+// always in flight, requests counted (`vmcnt(6)`: each wave sends six 1 KiB pieces per stage), ONE barrier per K-step.
+//   iteration t:  wait until stage t has landed | barrier | request stage t + 2 into the slot stage t - 1 left | 36 MFMAs on stage t
+// (the barrier both publishes stage t and proves every wave is past its reads of stage t - 1).
+// Image = 64 k-rows x 128 B, 32-byte slots XOR-ed by bits 1 and 3 of the k-row: the eight rows {0..3, 8..11} a half-wave of a transposing
+// read touches land on eight different 32-byte windows of the 256-byte bank row (the phased kernel's k-strided image).
+// Waves 4 (rows) x 2 (columns), each 48 x 96 of the tile = 3 x 6 MFMA tiles, 72 accumulator registers.
+// Output: split-K partials straight from the accumulators into the deterministic workspace (or fp32 atomics without one), the same
+// slice layout and K-step chunks as the other split-K kernels, so sa_gemm_bf16's reduce launch serves it unchanged.
+constexpr int ST_TILE = 192;
+constexpr int ST_IMG = 64 * 64 * 2;                 // 8 KiB
+constexpr int ST_OPER = 3 * ST_IMG;                 // 24 KiB: the 192 columns of one operand
+constexpr int ST_STAGE = 2 * ST_OPER;               // 48 KiB
+constexpr int ST_NSTAGE = 3;
+constexpr int ST_LDS = ST_NSTAGE * ST_STAGE;        // 144 KiB
+
+__device__ __forceinline__ int st_swz(int krow) { return ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1); }
+
+// byte offset (inside an operand's three images) of the first transposing read of a lane's fragment for the 16 columns from `sub`
+// (k-step 0; the second read is 4 k-rows = 512 B on, k-step 1 is 32 k-rows = 4096 B on: neither changes the swizzle bits)
+__device__ __forceinline__ int st_frag_off(int sub, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int krow = 8 * g + (i >> 2);
+  const int col = (sub & 63) + 4 * (i & 3);
+  return (sub >> 6) * ST_IMG + krow * 128 + (((col >> 4) ^ st_swz(krow)) << 5) + (col & 15) * 2;
+}
+
+__device__ __forceinline__ bf16x8 st_frag(const char* oper, int off) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(oper + off));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(oper + off + 512));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware remap as in the other kernels; the K slice is the slowest index, so the tiles of one slice -- the workgroups that share
+  // the narrow operand's rows -- are neighbours on one XCD and fetch them from its L2 after the first miss
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int ks_id = lid / ntiles;
+  const int tile = lid - ks_id * ntiles;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * ST_TILE, n0 = tn * ST_TILE;
+
+  const int ksteps = (p.K + BK - 1) / BK;
+  const int chunk = (ksteps + p.split_k - 1) / p.split_k;
+  const int kt_begin = ks_id * chunk;
+  const int nk = min(ksteps, kt_begin + chunk) - kt_begin;
+  if (nk <= 0) return;                                       // (an empty trailing slice: the reduce skips it too)
+
+  // ---- requests: waves 0..3 fetch operand A (the output's rows), waves 4..7 operand B; wave-instruction e of a wave is piece
+  // 6 (wave & 3) + e of its operand's 24 (image = piece >> 3, k-rows 8 (piece & 7) + [0, 8)); lane = (k-row, 16-byte chunk)
+  const bool isb = wave >= 4;
+  const __amdgpu_buffer_rsrc_t rs = isb ? make_rsrc(p.B, p.b_bytes) : make_rsrc(p.A, p.a_bytes);
+  const uint32_t ld2 = (uint32_t)(isb ? p.ldb : p.lda) * 2u;
+  const int c0 = isb ? n0 : m0;
+  uint32_t rq[6];
+  int rq_lds[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    const int piece = 6 * (wave & 3) + e;
+    const int img = piece >> 3, krow = 8 * (piece & 7) + (lane >> 3);
+    const int chunk16 = (lane & 7) ^ (st_swz(krow) << 1);
+    rq[e] = (uint32_t)krow * ld2 + (uint32_t)(c0 + img * 64 + chunk16 * 8) * 2u;
+    rq_lds[e] = (isb ? ST_OPER : 0) + piece * 1024;
+  }
+  auto request = [&](int slot, int kt, bool valid) {
+    char* base = smem + slot * ST_STAGE;
+    const uint32_t k_off = (uint32_t)kt * (uint32_t)BK * ld2;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) lds_dma16<true>(rs, base + rq_lds[e], valid ? rq[e] + k_off : 0xFFFFFFF0u);
+  };
+
+  // ---- fragment offsets
+  int fa_off[3], fb_off[6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) fa_off[i] = st_frag_off(48 * wm + 16 * i, lane);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) fb_off[j] = ST_OPER + st_frag_off(96 * wn + 16 * j, lane);
+
+  f32x4 acc[3][6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  request(0, kt_begin, true);
+  request(1, kt_begin + 1, 1 < nk);
+  int slot = 0, fill = 2;
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // stage t is in (the six youngest pieces, stage t + 1, may still fly)
+    __syncthreads();
+    request(fill, kt_begin + t + 2, t + 2 < nk);
+    const char* st = smem + slot * ST_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[3], fb[6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fa[i] = st_frag(st, fa_off[i] + ks * 4096);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fb[j] = st_frag(st, fb_off[j] + ks * 4096);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    slot = slot == ST_NSTAGE - 1 ? 0 : slot + 1;
+    fill = fill == ST_NSTAGE - 1 ? 0 : fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the out-of-range requests of the last two iterations)
+
+  // ---- partials: lane owns rows m = 4 g + r of column n = c of each 16 x 16 tile
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int n = n0 + 96 * wn + 16 * j + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 48 * wm + 16 * i + 4 * g + r;
+        if (m < p.M && n < p.N) {
+          if (p.split_ws) p.split_ws[((int64_t)ks_id * p.M + m) * p.N + n] = p.alpha * acc[i][j][r];
+          else atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+        }
+      }
+    }
+}
+
+}  // namespace
+
+// the 192 x 192 streaming kernel for (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error
+int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
+  static bool cfg = false;
+  if (!cfg) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: 144 KiB of LDS per workgroup refused");
+      return 2;
+    }
+    cfg = true;
+  }
+  p.tiles_m = (p.M + ST_TILE - 1) / ST_TILE;
+  p.tiles_n = (p.N + ST_TILE - 1) / ST_TILE;
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
+  hipLaunchKernelGGL(gemm_tn_stream_kernel, grid, dim3(512), ST_LDS, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(192 streaming split-K)");
+  return 0;
+}

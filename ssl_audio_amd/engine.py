@@ -218,6 +218,18 @@ def grad_target(p):
 
 
 WGRAD256_MIN_TILES = int(os.environ.get("SA_WGRAD256_MIN", "9"))
+WGRAD_STREAM_MAX_TILES = int(os.environ.get("SA_WGRAD_STREAM", "16"))      # 0: off
+
+
+def stream_wgrad(N, K, rows):
+    """Does the weight gradient [N, K] over `rows` rows take the 192 x 192 streaming split-K kernel (csrc/gemm_stream.hip)?  Narrow
+    outputs whose operands should stream from HBM once: measured (scripts/bench_gemm.py + rocprofv3, 127 488 rows) d = 192: qkv 50 -> 38 us,
+    fc1 / fc2 62 -> 54, proj equal; d = 384 (the MAE decoder): qkv 173 -> ~135, fc1 / fc2 202 -> 175, but 384 x 384 (four tiles, each
+    operand fetched twice) 52 -> 58: stays on the 128^2 kernel; d = 768 is MFMA-bound and stays on the 256^2 kernel (276 vs 288 us)."""
+    t192 = ((N + 191) // 192) * ((K + 191) // 192)
+    if t192 > WGRAD_STREAM_MAX_TILES or 4 * N * K < 3 * t192 * 192 * 192 or rows < 4096:
+        return False
+    return min(N, K) <= 192 if t192 <= 4 else min(N, K) <= 384
 
 
 def _wgrad(dY16, X16, out):
@@ -227,6 +239,11 @@ def _wgrad(dY16, X16, out):
     # measured (scripts/bench_gemm.py): with >= 9 output tiles of 256 x 256 (d = 768: every block weight) the one-workgroup-per-CU
     # 256^2 split-K tile wins (halved operand traffic, the long reduction hides its epilogue; proj at 9 tiles x 28 slices: 102 vs
     # 110 us); narrower outputs (ViT-T) stay on the 128^2 tile
+    if stream_wgrad(N, K, rows):
+        split = ops.pick_split_k(N, K, rows, tile=192)
+        if split > 1:
+            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=2)
+            return
     if ((N + 255) // 256) * ((K + 255) // 256) >= WGRAD256_MIN_TILES and rows >= 4096:
         split = ops.pick_split_k(N, K, rows, tile=256)
         if split > 1:

@@ -172,7 +172,7 @@ def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False
     bias + residual -> fp32 epilogue (proj / fc2 forward), which the forward layout runs on the phased kernel; epi1: the compact
     (bias ->) bf16 epilogue, phased too once the reduction is long (K >= 1536: the fc1 / qkv data gradients)."""
     if split_k > 1:
-        return "gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>"
+        return "gemm_tn_stream_kernel" if int(tile256) == 2 else ("gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>")
     big = M >= 1024 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
     if not big:
         return "gemm_kernel"
@@ -188,13 +188,13 @@ def pick_split_k(M, N, K, cu_count=None, tile=128):
         cu_count = CU_BUDGET or 256
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     ksteps = (K + 63) // 64
-    slots = (2 if tile == 128 else 1) * cu_count       # the 128^2 kernel runs two workgroups per CU, the 256^2 one
+    slots = (2 if tile == 128 else 1) * cu_count       # the 128^2 kernel runs two workgroups per CU, the 256^2 and 192^2 ones one
     if tiles >= slots or ksteps < 16:
         return 1
     # time ~ (rounds of resident workgroups) x (K-iterations per workgroup + fill/epilogue): a split that leaves the last
     # round nearly empty (e.g. 576 workgroups on 512 slots) costs a whole extra round, so search instead of doubling
     best, best_cost = 1, None
-    for s in range(1, min(128, ksteps // 4) + 1):
+    for s in range(1, min(int(os.environ.get("SA_SPLIT_MAX", "256")) if tile == 192 else 128, ksteps // 4) + 1):
         rounds = -(-tiles * s // slots)
         cost = rounds * (-(-ksteps // s) + 8)
         if best_cost is None or cost < best_cost:

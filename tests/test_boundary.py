@@ -266,3 +266,20 @@ def test_custom_ops_cover_every_compute_entry_point():
         assert f"lib().{sym}(" in src, (name, sym)                                                           # ... and reaches the symbol it names
     with pytest.raises(NotImplementedError):
         torch.ops.ssl_audio.axpy(torch.zeros(4), torch.ones(4), 2.0)
+
+
+def test_weight_gradient_kernel_selection():
+    """engine.stream_wgrad: which weight gradients (models/mae.py:106-129,149-163's Linear layers) take the 192 x 192 streaming split-K
+    kernel -- ViT-T's four block shapes and the MAE decoder's wide ones; square d = 384, padded outputs, short reductions and d = 768 do
+    not -- and the split ops.pick_split_k gives it fills one workgroup per CU without a nearly empty last round."""
+    from ssl_audio_amd import engine, ops
+    rows = 127488
+    for shape in [(576, 192), (192, 192), (768, 192), (192, 768), (1152, 384), (1536, 384), (384, 1536), (384, 1024)]:
+        assert engine.stream_wgrad(*shape, rows), shape
+    for shape in [(384, 384), (192, 256), (256, 384), (2304, 768), (768, 768), (768, 3072), (8192, 192)]:
+        assert not engine.stream_wgrad(*shape, rows), shape
+    assert not engine.stream_wgrad(576, 192, 2048)
+    for N, K in [(576, 192), (192, 192), (768, 192), (1152, 384)]:
+        tiles = ((N + 191) // 192) * ((K + 191) // 192)
+        split = ops.pick_split_k(N, K, rows, cu_count=256, tile=192)
+        assert 128 < tiles * split <= 256 or (tiles * split) % 256 > 192, (N, K, split)
