@@ -9,6 +9,7 @@
 // and wgrad (TN) are the same kernel and no transposed copy of a weight or activation is ever made.
 // LDS destination of an LDS-DMA is lane-linear, so swizzles are applied to the per-lane SOURCE address
 // and again on the fragment read (cdna_hip_programming.md rule 21).
+#include <string.h>
 #include "gemm_common.h"
 
 int sagemm::g_cu_budget = 0;
@@ -1216,6 +1217,17 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   const bool nt_phase = a->a_kmajor && a->b_kmajor && a->K >= 2 * BK &&
                         (p.epi_kind == 3 || (p.epi_kind == 1 && k1_min > 0 && (a->K >= k1_min || (a->N <= 256 && a->K >= 512))));
   char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : (nt_phase ? 'A' : '6')) : '1');
+  // mode P (gemm_pair.hip): 128 x 256 tiles, two 4-wave workgroups per CU -- one's epilogue under the other's main loop
+  static const char* pair_env = getenv("SA_GEMM_PAIR");        // experiment knob: list of epilogue kinds that take mode P, e.g. "36"
+  if (!force && big && pair_env && a->a_kmajor && a->b_kmajor && p.epi_kind > 0 && p.epi_kind < 10 && strchr(pair_env, '0' + p.epi_kind)) mode = 'P';
+  if (mode == 'P' && a->split_k == 1) {
+    if (a->a_kmajor && a->b_kmajor && big) {
+      SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+      const int rc = sagemm::launch_pair(p, stream);
+      if (rc >= 0) return rc;
+    }
+    mode = big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : (nt_phase ? 'A' : '6')) : '1';
+  }
   if (mode == 'A' && a->split_k == 1 && a->K >= 2 * BK && p.epi_kind != 0 && p.epi_kind != 2 && p.epi_kind != 4) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
     const int rc = sagemm::launch_phase(p, a->a_kmajor, a->b_kmajor, false, stream);

@@ -52,6 +52,8 @@ int* next_tile_counter(hipStream_t stream);
 int launch_phase(GemmParams p, bool a_kmajor, bool b_kmajor, bool split, hipStream_t stream);
 // gemm_stream.hip: the 192 x 192 streaming split-K kernel (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error
 int launch_stream(GemmParams p, hipStream_t stream);
+// gemm_pair.hip: the 128 x 256 kernel with two workgroups per CU (both operands k-major, compact epilogue kinds 1/3/5/6/8); -1: not covered
+int launch_pair(GemmParams p, hipStream_t stream);
 }  // namespace sagemm
 using sagemm::GemmParams;
 using sagemm::budget_slots;
