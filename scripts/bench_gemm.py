@@ -43,6 +43,13 @@ for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16)
         sk = int(os.environ["SA_BENCH_SPLIT"])
     cases.append((f"wgrad TN {name} split{sk}{['', ' 256', ' 192 stream'][int(use256)]}",
                   lambda out=out, dy=dy, xx=xx, sk=sk, use256=use256: ops.gemm(dy, xx, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=sk, tile256=int(use256)), 2.0 * M * N * K))
+_grp = [(dy, xx, torch.zeros(N, K, device=dev)) for name, N, K, dy, xx in [("qkv", 3 * d, d, q16, x16), ("proj", d, d, x16, x16), ("fc1", 4 * d, d, h4, x16), ("fc2", d, 4 * d, x16, h4)]]
+if all(engine.stream_wgrad(o.shape[0], o.shape[1], M) for _, _, o in _grp):
+    # the block's four weight gradients as ONE launch pair (engine.WgradGroup)
+    _tiles = sum(((o.shape[0] + 191) // 192) * ((o.shape[1] + 191) // 192) for _, _, o in _grp)
+    _sk = int(os.environ.get("SA_BENCH_SPLIT", "0")) or ops.pick_split_k(0, 0, M, tile=192, tiles=_tiles)
+    cases.append((f"wgrad TN block group of 4 split{_sk}", lambda: ops.gemm_wgrad_group([j[0] for j in _grp], [j[1] for j in _grp], [j[2] for j in _grp], _sk),
+                  sum(2.0 * M * o.shape[0] * o.shape[1] for _, _, o in _grp)))
 only = sys.argv[1] if len(sys.argv) > 1 else None
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 tot_t = tot_f = 0.0
@@ -56,6 +63,8 @@ for name, fn, fl in cases:
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    tot_t += ms; tot_f += fl
+    if "group" not in name:                                # (the block total keeps its twelve launches)
+        tot_t += ms; tot_f += fl
     print(f"{name:30s} {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s")
-print(f"ALL (one block's fwd+bwd GEMMs, tile={os.environ.get('SA_GEMM_TILE', 'default')}): {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
+if tot_t > 0:
+    print(f"ALL (one block's fwd+bwd GEMMs, tile={os.environ.get('SA_GEMM_TILE', 'default')}): {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")

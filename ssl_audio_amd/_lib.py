@@ -37,6 +37,7 @@ _SIGNATURES = {
     "sa_abi_version": [],
     "sa_device_info": [C.c_char_p, I32, C.POINTER(I32)],
     "sa_gemm_bf16": [C.POINTER(SaGemmArgs), P],
+    "sa_gemm_wgrad_group": [C.POINTER(SaGemmArgs), I32, P],
     "sa_cast_f32_to_bf16": [P, P, I64, P],
     "sa_cast_bf16_to_f32": [P, P, I64, P],
     "sa_transpose_bf16": [P, I32, I32, P, P],

@@ -1287,6 +1287,39 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
 }
 }  // namespace
 
+extern "C" int sa_gemm_wgrad_group(const SaGemmArgs* args, int32_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SA_CHECK_ARG(args != nullptr && n >= 1 && n <= sagemm::STREAM_MAX_PROBLEMS, "sa_gemm_wgrad_group: 1 .. %d products", sagemm::STREAM_MAX_PROBLEMS);
+  sagemm::StreamGroup g = {};
+  g.n = n; g.K = args[0].K; g.split_k = args[0].split_k; g.alpha = args[0].alpha;
+  const bool det = args[0].splitk_ws != nullptr;
+  const int64_t lim = (int64_t)1 << 32;
+  for (int i = 0; i < n; ++i) {
+    const SaGemmArgs* a = args + i;
+    SA_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->A && a->B && a->out_f32, "sa_gemm_wgrad_group: product %d: empty problem or null pointer", i);
+    SA_CHECK_ARG(!a->a_kmajor && !a->b_kmajor, "sa_gemm_wgrad_group: product %d: both operands must be k-strided ([K][M] and [K][N])", i);
+    SA_CHECK_ARG(a->K == g.K && a->split_k == g.split_k && a->alpha == g.alpha && a->split_k > 1,
+                 "sa_gemm_wgrad_group: product %d: K, alpha and split_k (> 1) must be the same in the whole group", i);
+    SA_CHECK_ARG(!a->out_bf16 && !a->bias && !a->act && !a->residual && !a->row_group && !a->colsum_out,
+                 "sa_gemm_wgrad_group: product %d: only alpha and fp32 accumulation are supported", i);
+    SA_CHECK_ARG(a->lda % 8 == 0 && a->ldb % 8 == 0 && ((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0,
+                 "sa_gemm_wgrad_group: product %d: operands must be 16-byte aligned with leading dimensions that are multiples of 8", i);
+    SA_CHECK_ARG((a->splitk_ws != nullptr) == det, "sa_gemm_wgrad_group: splitk_ws must be set in every product or in none");
+    if (det) SA_CHECK_ARG(a->N % 4 == 0 && a->ldo_f32 % 4 == 0 && (((uintptr_t)a->splitk_ws | (uintptr_t)a->out_f32) & 15) == 0,
+                          "sa_gemm_wgrad_group: product %d: the workspace form needs N %% 4 == 0 and 16-byte aligned fp32 rows", i);
+    SA_CHECK_ARG(((int64_t)a->K + 512) * a->lda * 2 < lim && ((int64_t)a->K + 512) * a->ldb * 2 < lim, "sa_gemm_wgrad_group: product %d: operand too large", i);
+    sagemm::StreamProb& q = g.pr[i];
+    q.A = (const char*)a->A; q.B = (const char*)a->B;
+    q.a_bytes = (uint32_t)((((int64_t)a->K - 1) * a->lda + a->M) * 2);
+    q.b_bytes = (uint32_t)((((int64_t)a->K - 1) * a->ldb + a->N) * 2);
+    q.lda = (int)a->lda; q.ldb = (int)a->ldb; q.M = a->M; q.N = a->N;
+    q.ws = a->splitk_ws; q.out = a->out_f32; q.ldo = a->ldo_f32;
+  }
+  const int rc = sagemm::launch_stream_group(g, stream);
+  if (rc != 0 || !det) return rc;
+  return sagemm::launch_stream_reduce(g, stream);
+}
+
 namespace {
 // dst[c][r] = src[r][c] for a bf16 [R][C] matrix: 64 x 64 tiles through LDS (padded rows: no bank conflicts), 16-byte global accesses
 __device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ src, int R, int Cn, bf16_t* __restrict__ dst, int tr, int tc,

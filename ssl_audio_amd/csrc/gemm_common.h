@@ -50,8 +50,26 @@ int* next_tile_counter(hipStream_t stream);
 // gemm_phase.hip: launches the phased kernel for (layout, split) if it covers the problem (compact epilogue kinds 1/3/5/6 or split-K
 // atomics); returns -1 when it does not, 0 on success, 2 on a launch error
 int launch_phase(GemmParams p, bool a_kmajor, bool b_kmajor, bool split, hipStream_t stream);
-// gemm_stream.hip: the 192 x 192 streaming split-K kernel (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error
+// gemm_stream.hip: the 192 x 192 streaming split-K kernel (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error.
+// One launch serves up to STREAM_MAX_PROBLEMS products over the SAME reduction (a transformer block's four weight gradients): the
+// workgroups -- and with them the fp32 partial tiles the split costs, one per workgroup -- are shared out over all of them.
+constexpr int STREAM_MAX_PROBLEMS = 8;
+struct StreamProb {
+  const char* A; const char* B;    // [K][M], [K][N] bf16 (k-strided)
+  float* ws;                       // [split_k][M][N] partials, or null: fp32 atomics into out
+  float* out; int64_t ldo;
+  uint32_t a_bytes, b_bytes;
+  int lda, ldb, M, N;
+  int tile0, tiles_m, rblock0;     // filled by launch_stream_group: first tile / first reduce block of this product
+};
+struct StreamGroup {
+  StreamProb pr[STREAM_MAX_PROBLEMS];
+  int n, ntiles, K, split_k;
+  float alpha;
+};
 int launch_stream(GemmParams p, hipStream_t stream);
+int launch_stream_group(StreamGroup& g, hipStream_t stream);
+int launch_stream_reduce(const StreamGroup& g, hipStream_t stream);
 // gemm_pair.hip: the 128 x 256 kernel with two workgroups per CU (both operands k-major, compact epilogue kinds 1/3/5/6/8); -1: not covered
 int launch_pair(GemmParams p, hipStream_t stream);
 }  // namespace sagemm

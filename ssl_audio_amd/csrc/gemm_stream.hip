@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8 st_frag(const char* oper, int off) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const sagemm::StreamGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -60,14 +60,19 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p)
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int ks_id = lid / ntiles;
-  const int tile = lid - ks_id * ntiles;
+  const int ks_id = lid / grp.ntiles;
+  const int gtile = lid - ks_id * grp.ntiles;
+  int pi = 0;                                                // the product this tile belongs to (a launch carries up to eight: see launch_stream_group)
+#pragma unroll
+  for (int i = 1; i < sagemm::STREAM_MAX_PROBLEMS; ++i)
+    if (i < grp.n && gtile >= grp.pr[i].tile0) pi = i;
+  const sagemm::StreamProb& p = grp.pr[pi];
+  const int tile = gtile - p.tile0;
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
   const int m0 = tm * ST_TILE, n0 = tn * ST_TILE;
 
-  const int ksteps = (p.K + BK - 1) / BK;
-  const int chunk = (ksteps + p.split_k - 1) / p.split_k;
+  const int ksteps = (grp.K + BK - 1) / BK;
+  const int chunk = (ksteps + grp.split_k - 1) / grp.split_k;
   const int kt_begin = ks_id * chunk;
   const int nk = min(ksteps, kt_begin + chunk) - kt_begin;
   if (nk <= 0) return;                                       // (an empty trailing slice: the reduce skips it too)
@@ -135,6 +140,11 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p)
 
   // ---- partials: lane owns rows m = 4 g + r of column n = c of each 16 x 16 tile
   const int g = lane >> 4, c = lane & 15;
+  const int M = p.M, N = p.N;
+  float* const ws = p.ws;
+  float* const out = p.out;
+  const int64_t ldo = p.ldo;
+  const float alpha = grp.alpha;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -143,18 +153,67 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const GemmParams p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + 48 * wm + 16 * i + 4 * g + r;
-        if (m < p.M && n < p.N) {
-          if (p.split_ws) p.split_ws[((int64_t)ks_id * p.M + m) * p.N + n] = p.alpha * acc[i][j][r];
-          else atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n, p.alpha * acc[i][j][r]);
+        if (m < M && n < N) {
+          if (ws) ws[((int64_t)ks_id * M + m) * N + n] = alpha * acc[i][j][r];
+          else atomicAdd(out + (int64_t)m * ldo + n, alpha * acc[i][j][r]);
         }
       }
     }
 }
 
+// deterministic split-K, second launch, for a whole group: out_i[m][n] += sum over slices (in slice order) of ws_i[s][m][n].  One
+// block = 64 float4 columns of one product (blocks are dealt to the products in order); its eight waves take every eighth slice, their
+// partial sums meet in LDS and are added in wave order (sa_gemm_bf16's splitk_reduce_wide_kernel, with a product table in front).
+__global__ __launch_bounds__(512) void stream_reduce_kernel(const sagemm::StreamGroup grp, int nslice) {
+  constexpr int NW = 8;
+  __shared__ float4 part[NW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < sagemm::STREAM_MAX_PROBLEMS; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.pr[i].rblock0) pi = i;
+  const sagemm::StreamProb& p = grp.pr[pi];
+  const int M = p.M, N = p.N;
+  const int64_t i4 = (int64_t)((int)blockIdx.x - p.rblock0) * 64 + lane;
+  const int n4 = N >> 2;
+  const bool ok = i4 < (int64_t)M * n4;
+  const int m = ok ? (int)(i4 / n4) : 0, n = ok ? (int)(i4 - (int64_t)m * n4) * 4 : 0;
+  const int64_t slice = (int64_t)M * N;
+  const float* src = p.ws + (int64_t)m * N + n;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int s = wave;
+    for (; s + 3 * NW < nslice; s += 4 * NW) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + s * slice), v1 = *reinterpret_cast<const float4*>(src + (s + NW) * slice),
+                   v2 = *reinterpret_cast<const float4*>(src + (s + 2 * NW) * slice), v3 = *reinterpret_cast<const float4*>(src + (s + 3 * NW) * slice);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; s < nslice; s += NW) {
+      const float4 v = *reinterpret_cast<const float4*>(src + s * slice);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0 || !ok) return;
+  float4* o = reinterpret_cast<float4*>(p.out + (int64_t)m * p.ldo + n);
+  float4 t = *o;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float4 v = part[w][lane];
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  *o = t;
+}
+
 }  // namespace
 
-// the 192 x 192 streaming kernel for (both operands k-strided, split_k > 1); 0 on success, 2 on a launch error
-int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
+// the 192 x 192 streaming kernel for `g.n` products that share the reduction (both operands k-strided, split_k > 1); fills in the tile
+// bookkeeping of `g`.  0 on success, 2 on a launch error
+int sagemm::launch_stream_group(StreamGroup& g, hipStream_t stream) {
   static bool cfg = false;
   if (!cfg) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess) {
@@ -163,10 +222,37 @@ int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
     }
     cfg = true;
   }
-  p.tiles_m = (p.M + ST_TILE - 1) / ST_TILE;
-  p.tiles_n = (p.N + ST_TILE - 1) / ST_TILE;
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k));
-  hipLaunchKernelGGL(gemm_tn_stream_kernel, grid, dim3(512), ST_LDS, stream, p);
+  int tiles = 0, rblocks = 0;
+  for (int i = 0; i < g.n; ++i) {
+    StreamProb& q = g.pr[i];
+    q.tiles_m = (q.M + ST_TILE - 1) / ST_TILE;
+    q.tile0 = tiles;
+    tiles += q.tiles_m * ((q.N + ST_TILE - 1) / ST_TILE);
+    q.rblock0 = rblocks;
+    rblocks += (int)(((int64_t)q.M * (q.N / 4) + 63) / 64);
+  }
+  g.ntiles = tiles;
+  hipLaunchKernelGGL(gemm_tn_stream_kernel, dim3((unsigned)(tiles * g.split_k)), dim3(512), ST_LDS, stream, g);
   SA_LAUNCH_CHECK("sa_gemm_bf16(192 streaming split-K)");
   return 0;
+}
+
+// the reduce launch of a group whose partials went to workspaces (every product's `ws` set)
+int sagemm::launch_stream_reduce(const StreamGroup& g, hipStream_t stream) {
+  const int ksteps = (g.K + BK - 1) / BK, chunk = (ksteps + g.split_k - 1) / g.split_k;
+  const int nslice = (ksteps + chunk - 1) / chunk;           // trailing slices with an empty K range wrote nothing
+  const StreamProb& last = g.pr[g.n - 1];
+  const int rblocks = last.rblock0 + (int)(((int64_t)last.M * (last.N / 4) + 63) / 64);
+  hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)rblocks), dim3(512), 0, stream, g, nslice);
+  SA_LAUNCH_CHECK("sa_gemm_wgrad_group(split-K reduce)");
+  return 0;
+}
+
+int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
+  StreamGroup g = {};
+  g.n = 1; g.K = p.K; g.split_k = p.split_k; g.alpha = p.alpha;
+  StreamProb& q = g.pr[0];
+  q.A = p.A; q.B = p.B; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N;
+  q.ws = p.split_ws; q.out = p.out_f32; q.ldo = p.ldo_f32;
+  return launch_stream_group(g, stream);
 }

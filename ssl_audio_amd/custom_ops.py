@@ -25,6 +25,7 @@ SCHEMAS = {
              "Tensor? aux_in=None, Tensor(a!)? aux_out=None, Tensor? residual=None, int res_mod=0, Tensor(b!)? out_f32=None, "
              "Tensor(c!)? out_bf16=None, int row_group=0, int split_k=1, bool accumulate=False, bool tile256=False, "
              "Tensor(d!)? colsum_out=None) -> ()"),
+    "gemm_wgrad_group": ("sa_gemm_wgrad_group", "(Tensor[] dY, Tensor[] X, Tensor(a!)[] out, int split_k) -> ()"),
     "transpose_bf16": ("sa_transpose_bf16", "(Tensor src, Tensor(a!) dst) -> ()"),
     # (the matrices written are named by pointers inside `desc`; the schema marks desc so that the operator counts as one with a side effect)
     "transpose_bf16_batch": ("sa_transpose_bf16_batch", "(Tensor(a!) desc, int n_tiles) -> ()"),
@@ -172,8 +173,9 @@ def register():
         def bump(keyset, *args, _op=op, _written=written, _names=[n for n, _ in names], **kwargs):
             for i in _written:
                 t = args[i] if i < len(args) else kwargs.get(_names[i])
-                if t is not None:
-                    torch.autograd.graph.increment_version(t)
+                for tt in (t if isinstance(t, (list, tuple)) else (t,)):
+                    if tt is not None:
+                        torch.autograd.graph.increment_version(tt)
             with torch._C._AutoDispatchBelowADInplaceOrView():
                 return _op.redispatch(keyset & torch._C._after_ADInplaceOrView_keyset, *args, **kwargs)
 

@@ -256,6 +256,41 @@ def _wgrad(dY16, X16, out):
         ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, accumulate=True)
 
 
+WGRAD_GROUP = os.environ.get("SA_WGRAD_GROUP", "1") != "0"
+
+
+class WgradGroup:
+    """The weight gradients of one transformer block's backward, launched TOGETHER at its end when they are the streaming kernel's kind
+    (narrow outputs over the same rows: ViT-T's qkv / proj / fc1 / fc2, the MAE decoder's wide ones).  Split-K costs one fp32 partial
+    tile per workgroup, and a launch wants a workgroup per CU: four launches write and re-read four chips' worth of partials (148 MB
+    per ViT-T block against 784 MB of operands), one group launch a quarter of that (ops.gemm_wgrad_group).  Everything else goes out
+    at once through `_wgrad`.  The operands stay referenced until `flush()`."""
+    __slots__ = ("jobs",)
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dY16, X16, out):
+        N, K = out.shape
+        rows = dY16.shape[0]
+        if WGRAD_GROUP and stream_wgrad(N, K, rows) and len(self.jobs) < 8 and (not self.jobs or self.jobs[0][0].shape[0] == rows):
+            self.jobs.append((dY16, X16, out))
+        else:
+            _wgrad(dY16, X16, out)
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if len(jobs) > 1:
+            rows = jobs[0][0].shape[0]
+            tiles = sum(((o.shape[0] + 191) // 192) * ((o.shape[1] + 191) // 192) for _, _, o in jobs)
+            split = ops.pick_split_k(0, 0, rows, tile=192, tiles=tiles)
+            if split > 1:
+                ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], split)
+                return
+        for j in jobs:
+            _wgrad(*j)
+
+
 class BlockParams:
     """Views of one transformer block's parameters (fp32 masters) -- key names follow models/mae.py."""
     __slots__ = ("n1w", "n1b", "wqkv", "qb", "vb", "wp", "bp", "n2w", "n2b", "w1", "b1", "w2", "b2")
@@ -307,8 +342,9 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     M, d = x.shape
     dev = x.device
     W = BF16_WEIGHTS.get
+    wg = WgradGroup()        # the four weight gradients leave together (before LN1's backward reuses dx2_16's storage)
     # fc2
-    _wgrad(dx3_16, a, g.w2)
+    wg.add(dx3_16, a, g.w2)
     if not b2_done:
         ops.colsum_bf16(dx3_16, g.b2, accumulate=True)
     dpre = torch.empty_like(pre)
@@ -316,7 +352,7 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     w2b, w2k = _dgrad_w(p.w2)
     ops.gemm(dx3_16, w2b, b_kmajor=w2k, act=4 if _ACT_PAIR else 2, aux_in=pre, out_bf16=dpre, colsum_out=g.b1 if fuse_b1 else None)   # (dY W2) * GELU'(pre)
     # fc1
-    _wgrad(dpre, h2, g.w1)
+    wg.add(dpre, h2, g.w1)
     if not fuse_b1:
         ops.colsum_bf16(dpre, g.b1, accumulate=True)
     dh2 = torch.empty(M, d, dtype=BF16, device=dev)
@@ -328,7 +364,7 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     dx2_16 = torch.empty(M, d, dtype=BF16, device=dev)
     ops.layernorm_bwd(dh2, x2, p.n2w, mean2, rstd2, dres=dx3, dx_f32=dx2, dx_bf16=dx2_16, dgamma=g.n2w, dbeta=g.n2b, dxsum=g.bp)
     # proj
-    _wgrad(dx2_16, ao, g.wp)
+    wg.add(dx2_16, ao, g.wp)
     dao = dh2  # reuse
     wpb, wpk = _dgrad_w(p.wp)
     ops.gemm(dx2_16, wpb, b_kmajor=wpk, out_bf16=dao)
@@ -336,7 +372,8 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv)
     # qkv
-    _wgrad(dqkv, h1, g.wqkv)
+    wg.add(dqkv, h1, g.wqkv)
+    wg.flush()
     ops.colsum_qv(dqkv, d, g.qb, g.vb)
     dh1 = dao
     wqb, wqk = _dgrad_w(p.wqkv)

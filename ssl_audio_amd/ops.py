@@ -166,6 +166,43 @@ def set_dynamic_tiles(on):
     check(lib().sa_set_dynamic_tiles(int(bool(on))), "sa_set_dynamic_tiles")
 
 
+def gemm_wgrad_group(dY, X, out, split_k):
+    """dY[i] [rows, N_i] bf16, X[i] [rows, K_i] bf16, out[i] [N_i, K_i] fp32, all over the same rows: out_i += dY_i^T X_i for the whole
+    group in ONE pair of launches of the 192 x 192 streaming kernel (include/ssl_audio_hip.h: sa_gemm_wgrad_group) -- the four weight
+    gradients of a transformer block at backward (models/mae.py:106-129,149-163)."""
+    jobs = list(zip(dY, X, out))
+    n = len(jobs)
+    arr = (SaGemmArgs * n)()
+    rows = jobs[0][0].shape[0]
+    sizes = [lib().sa_gemm_splitk_workspace_bytes(dY.shape[1], X.shape[1], split_k) for dY, X, _ in jobs]
+    det = DETERMINISTIC_WGRAD and all(X.shape[1] % 4 == 0 for _, X, _ in jobs)
+    ws = _workspace(sum((s + 255) // 256 * 256 for s in sizes), jobs[0][0].device, "gemm_splitk_group") if det else None
+    off, flops, nbytes = 0, 0.0, 0.0
+    for a, (dY, X, out), size in zip(arr, jobs, sizes):
+        _req(dY, BF16, "dY"), _req(X, BF16, "X"), _req(out, F32, "out")
+        (ra, M, lda), (rb, N, ldb) = _rows(dY, "dY"), _rows(X, "X")
+        if ra != rows or rb != rows or tuple(out.shape) != (M, N):
+            raise ValueError(f"gemm_wgrad_group: dY {tuple(dY.shape)}, X {tuple(X.shape)}, out {tuple(out.shape)} do not form out = dY^T X over {rows} rows")
+        a.A, a.lda, a.a_kmajor = dY.data_ptr(), lda, 0
+        a.B, a.ldb, a.b_kmajor = X.data_ptr(), ldb, 0
+        a.M, a.N, a.K, a.alpha = M, N, rows, 1.0
+        a.out_f32, a.ldo_f32 = out.data_ptr(), _rows(out, "out")[2]
+        a.split_k, a.tile256 = split_k, 2
+        if det:
+            a.splitk_ws = ws.data_ptr() + off
+            off += (size + 255) // 256 * 256
+        flops += 2.0 * M * N * rows
+        nbytes += 2.0 * (M + N) * rows + 4.0 * M * N
+    if GEMM_PROFILE is None:
+        check(lib().sa_gemm_wgrad_group(arr, n, _stream()), "sa_gemm_wgrad_group")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().sa_gemm_wgrad_group(arr, n, _stream()), "sa_gemm_wgrad_group")
+    e1.record()
+    GEMM_PROFILE.append((e0, e1, flops, "TN/splitk", nbytes, "gemm_tn_stream_kernel", f"gemm_tn_stream_kernel<group of {n}>"))
+
+
 def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False, epi1=False):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
     override); used to label bench.py's per-launch timings with the names rocprofv3 reports.  epi3: the launch has the compact
@@ -182,11 +219,13 @@ def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False
     return "gemm256_phase_kernel" if phased else "gemm256_persist_kernel"
 
 
-def pick_split_k(M, N, K, cu_count=None, tile=128):
-    """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist."""
+def pick_split_k(M, N, K, cu_count=None, tile=128, tiles=None):
+    """Split the reduction of a wgrad-shaped GEMM (few output tiles, long K) until ~2 waves of workgroups exist.  `tiles`: the tile
+    count of a whole group of products over the same K (gemm_wgrad_group) instead of the one [M, N] output's."""
     if cu_count is None:
         cu_count = CU_BUDGET or 256
-    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
+    if tiles is None:
+        tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile)
     ksteps = (K + 63) // 64
     slots = (2 if tile == 128 else 1) * cu_count       # the 128^2 kernel runs two workgroups per CU, the 256^2 and 192^2 ones one
     if tiles >= slots or ksteps < 16:

@@ -25,8 +25,13 @@ def cast_f32_from_bf16(src, dst):
     return dst
 
 
-def pick_split_k(M, N, K, cu_count=None, tile=128):
+def pick_split_k(M, N, K, cu_count=None, tile=128, tiles=None):
     return 1
+
+
+def gemm_wgrad_group(dY, X, out, split_k):
+    for dy, x, o in zip(dY, X, out):
+        o += dy.float().t() @ x.float()
 
 
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None, res_mod=0,

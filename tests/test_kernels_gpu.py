@@ -165,6 +165,42 @@ def test_gemm_streaming_narrow_wgrad(dev, N, K):
         assert rel_err(out, o2.double().cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("det", [True, False])
+def test_gemm_wgrad_group(dev, det, monkeypatch):
+    """sa_gemm_wgrad_group: the four weight gradients of a ViT-T block (models/mae.py:106-129,149-163 at backward: qkv 576 x 192, proj
+    192 x 192, fc1 768 x 192, fc2 192 x 768) over the same rows in ONE pair of launches, accumulated into non-zero buffers: against fp64
+    on the same bf16 operands, against the four single launches, twice bit for bit (workspace form); also a group with strided operands
+    (dq / dv column ranges of a packed dqkv), ragged outputs, a reduction that is no multiple of 64 and one-K-step slices; and the
+    argument checks (mixed reductions, a k-major operand, nine products)."""
+    monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", det)
+    d = 192
+    for rows, split in [(127488 // 8, 21), (64 * 21, 21), (64 * 9 + 40, 5)]:
+        dqkv, h1 = bf(rnd((rows, 3 * d), 91)).to(dev), bf(rnd((rows, d), 92)).to(dev)
+        dx2, ao = bf(rnd((rows, d), 93)).to(dev), bf(rnd((rows, d), 94)).to(dev)
+        dpre, h2 = bf(rnd((rows, 4 * d), 95)).to(dev), bf(rnd((rows, d), 96)).to(dev)
+        dx3, a = bf(rnd((rows, d), 97)).to(dev), bf(rnd((rows, 4 * d), 98)).to(dev)
+        jobs = [(dx3, a), (dpre, h2), (dx2, ao), (dqkv, h1), (dqkv[:, 2 * d:], ao[:, :136])]      # (the last: strided dY, ragged 192 x 136 output)
+        base = [torch.randn(dy.shape[1], x.shape[1], device=dev) for dy, x in jobs]
+        runs = []
+        for _ in range(2):
+            outs = [b.clone() for b in base]
+            ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], outs, split)
+            runs.append(outs)
+        for (dy, x), b, o, o2 in zip(jobs, base, runs[0], runs[1]):
+            ref = b.double().cpu() + dy.double().cpu().T @ x.double().cpu()
+            assert rel_err(o, ref) < 1e-5, (rows, split, tuple(o.shape))
+            if det:
+                assert torch.equal(o, o2)
+            single = b.clone()
+            ops.gemm(dy, x, a_kmajor=False, b_kmajor=False, out_f32=single, split_k=split, tile256=2)
+            assert rel_err(o, single.double().cpu()) < 1e-6
+    o = [torch.zeros(d, d, device=dev), torch.zeros(d, d, device=dev)]
+    with pytest.raises((RuntimeError, ValueError), match="same in the whole group|do not form"):
+        ops.gemm_wgrad_group([dx2, dx2[:320]], [ao, ao[:320]], o, 4)
+    with pytest.raises(RuntimeError, match="1 .. 8 products"):
+        ops.gemm_wgrad_group([dx2] * 9, [ao] * 9, [o[0]] * 9, 4)
+
+
 @pytest.mark.parametrize("env", [{}, {"SA_GEMM_TILE": "6"}, {"SA_GEMM_TILE": "8", "SA_GEMM_WGRAD_RING": "1"}, {"SA_GEMM_TILE": "1"},
                                  {"SA_GEMM_TILE": "A", "SA_GEMM_WGRAD_PHASE": "1"}, {"SA_GEMM_TILE": "P"}])
 def test_gemm_tile_modes(dev, env):
