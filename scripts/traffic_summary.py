@@ -8,6 +8,7 @@ def family(name):
     if "colsum" in name or "gemm" not in name:
         return None
     if "gemm_tn_stream_kernel" in name: return "gemm_tn_stream_kernel"
+    if "gemm_tn_stream256_kernel" in name: return "gemm_tn_stream256_kernel"
     if "gemm256_phase_kernel" in name: return "gemm256_phase_kernel"
     if "gemm256_persist_kernel" in name: return "gemm256_persist_kernel"
     if "gemm256_ring_kernel" in name: return "gemm256_ring_kernel<split-K>" if "true>(" in name.split("gemm256_ring_kernel")[1][:24].replace(" ", "").split(",")[-1] else "gemm256_ring_kernel"

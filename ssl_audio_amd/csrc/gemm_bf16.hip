@@ -1257,6 +1257,11 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   }
   if (a->split_k > 1 && a->tile256) {
     SA_CHECK_ARG((a_rows + 512) * a->lda * 2 < lim && (b_rows + 512) * a->ldb * 2 < lim, "sa_gemm_bf16: operand too large for the 256 tile");
+    // TN (weight gradients): the four-stage ring of gemm_stream.hip, default since round 5 (three 32 KiB stages in flight against one
+    // 64 KiB stage: fc1 / fc2 282 -> 271 us, qkv 247 -> 243, proj 71 -> 75; ViT-B step 40.94 -> 40.27 ms; SA_GEMM_WGRAD_STREAM256=0: the
+    // two-stage kernel below)
+    static const char* wstream = getenv("SA_GEMM_WGRAD_STREAM256");
+    if (!(wstream && wstream[0] == '0') && !a->a_kmajor && !a->b_kmajor && (!p.split_ws || a->N % 4 == 0)) return sagemm::launch_stream256(p, stream);
     static const char* wphase = getenv("SA_GEMM_WGRAD_PHASE");
     if (!p.split_ws && wphase && wphase[0] == '1' && !a->a_kmajor && !a->b_kmajor && (a->K + BK - 1) / BK / a->split_k >= 2)
       return sagemm::launch_phase(p, false, false, true, stream);

@@ -161,6 +161,134 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const sagemm::Strea
     }
 }
 
+// =====================================================================================================
+// The same ring for WIDE weight gradients (d = 768 / 1024: MFMA-bound, 256 x 256 tile): four stages of 32-deep K-steps, 32 KiB each
+// (per operand four images of 32 k-rows x 64 columns), THREE stages = 96 KiB in flight, `vmcnt(8)` (four pieces per wave and stage),
+// one barrier per 32 MFMAs.  The k-strided layout keeps whole 512-byte row segments at BK = 32 (a k-major operand would be cut to 64-byte
+// ones: DESIGN.md round 2, finding 3).  Waves 2 x 4, each 128 x 64 (8 x 4 MFMA tiles, swapped operand order: a lane owns four
+// consecutive columns of a row, partials leave as float4).
+constexpr int SW_IMG = 32 * 64 * 2;                 // 4 KiB
+constexpr int SW_OPER = 4 * SW_IMG;                 // 16 KiB: 256 columns of one operand
+constexpr int SW_STAGE = 2 * SW_OPER;               // 32 KiB
+constexpr int SW_NSTAGE = 4;
+constexpr int SW_LDS = SW_NSTAGE * SW_STAGE;        // 128 KiB
+
+__device__ __forceinline__ int sw_frag_off(int sub, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int krow = 8 * g + (i >> 2);
+  const int col = (sub & 63) + 4 * (i & 3);
+  return (sub >> 6) * SW_IMG + krow * 128 + (((col >> 4) ^ st_swz(krow)) << 5) + (col & 15) * 2;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int ks_id = lid / ntiles;
+  const int tile = lid - ks_id * ntiles;
+  const int GM = p.gm256;
+  const int group_sz = GM * p.tiles_n;
+  const int grp = tile / group_sz, within = tile - grp * group_sz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tm = grp * GM + within % gm, tn = within / gm;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int ksteps = (p.K + BK - 1) / BK;                    // slices are cut at the 64-row K-steps of the other split-K kernels
+  const int chunk = (ksteps + p.split_k - 1) / p.split_k;
+  const int kt_begin = ks_id * chunk;
+  const int nk = 2 * (min(ksteps, kt_begin + chunk) - kt_begin);     // 32-deep stages
+  if (nk <= 0) return;
+
+  // ---- requests: waves 0..3 fetch operand A's image `wave`, waves 4..7 operand B's image `wave - 4`; piece e = k-rows 8 e + [0, 8)
+  const bool isb = wave >= 4;
+  const __amdgpu_buffer_rsrc_t rs = isb ? make_rsrc(p.B, p.b_bytes) : make_rsrc(p.A, p.a_bytes);
+  const uint32_t ld2 = (uint32_t)(isb ? p.ldb : p.lda) * 2u;
+  const int c0 = (isb ? n0 : m0) + (wave & 3) * 64;
+  uint32_t rq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int krow = 8 * e + (lane >> 3);
+    const int chunk16 = (lane & 7) ^ (st_swz(krow) << 1);
+    rq[e] = (uint32_t)krow * ld2 + (uint32_t)(c0 + chunk16 * 8) * 2u;
+  }
+  const int rq_lds = (isb ? SW_OPER : 0) + (wave & 3) * SW_IMG;
+  const uint32_t k_base = (uint32_t)kt_begin * (uint32_t)BK * ld2;
+  auto request = [&](int slot, int st, bool valid) {
+    char* base = smem + slot * SW_STAGE + rq_lds;
+    const uint32_t k_off = k_base + (uint32_t)st * 32u * ld2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lds_dma16<true>(rs, base + e * 1024, valid ? rq[e] + k_off : 0xFFFFFFF0u);
+  };
+
+  int fa_off[8], fb_off[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fa_off[i] = sw_frag_off(128 * wr + 16 * i, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb_off[j] = SW_OPER + sw_frag_off(64 * wc + 16 * j, lane);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  request(0, 0, true);
+  request(1, 1, 1 < nk);
+  request(2, 2, 2 < nk);
+  const bool late = (p.stagger & 8) && wr == 1;
+  const bool prio = (p.stagger & 16) != 0;
+  int slot = 0, fill = 3;
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // stage t is in; stages t + 1 and t + 2 may still fly
+    __syncthreads();
+    if (!late) request(fill, t + 3, t + 3 < nk);
+    const char* st = smem + slot * SW_STAGE;
+    bf16x8 fa[8], fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = st_frag(st, fb_off[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = st_frag(st, fa_off[i]);
+    if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
+    if (late) request(fill, t + 3, t + 3 < nk);              // (wave row 1: its share of the requests goes out behind its MFMAs)
+    slot = slot == SW_NSTAGE - 1 ? 0 : slot + 1;
+    fill = fill == SW_NSTAGE - 1 ? 0 : fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- partials: lane owns row 16 i + c, columns 16 j + 4 g + [0, 4) of its 128 x 64 block
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + 128 * wr + 16 * i + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 64 * wc + 16 * j + 4 * g;
+      if (m < p.M && n < p.N) {
+        if (p.split_ws) {
+          *reinterpret_cast<float4*>(p.split_ws + ((int64_t)ks_id * p.M + m) * p.N + n) =
+              make_float4(p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n + r, p.alpha * acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
 // deterministic split-K, second launch, for a whole group: out_i[m][n] += sum over slices (in slice order) of ws_i[s][m][n].  One
 // block = 64 float4 columns of one product (blocks are dealt to the products in order); its eight waves take every eighth slice, their
 // partial sums meet in LDS and are added in wave order (sa_gemm_bf16's splitk_reduce_wide_kernel, with a product table in front).
@@ -255,4 +383,21 @@ int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
   q.A = p.A; q.B = p.B; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N;
   q.ws = p.split_ws; q.out = p.out_f32; q.ldo = p.ldo_f32;
   return launch_stream_group(g, stream);
+}
+
+// the 256 x 256 form (both operands k-strided, split_k > 1); with a workspace N must be a multiple of 4 (float4 partial rows)
+int sagemm::launch_stream256(GemmParams p, hipStream_t stream) {
+  static bool cfg = false;
+  if (!cfg) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS) != hipSuccess) {
+      sa_set_error("sa_gemm_bf16: 128 KiB of LDS per workgroup refused");
+      return 2;
+    }
+    cfg = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL(gemm_tn_stream256_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split_k)), dim3(512), SW_LDS, stream, p);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(256 streaming split-K)");
+  return 0;
 }

@@ -203,13 +203,20 @@ def gemm_wgrad_group(dY, X, out, split_k):
     GEMM_PROFILE.append((e0, e1, flops, "TN/splitk", nbytes, "gemm_tn_stream_kernel", f"gemm_tn_stream_kernel<group of {n}>"))
 
 
+STREAM256 = os.environ.get("SA_GEMM_WGRAD_STREAM256", "1") != "0"      # (mirror of gemm_dispatch's default for TN split-K on the 256 tile)
+
+
 def gemm_kernel_family(M, N, K, a_kmajor, b_kmajor, split_k, tile256, epi3=False, epi1=False):
     """Which device kernel sa_gemm_bf16 dispatches to by default (mirror of the selection in gemm_bf16.hip, no SA_GEMM_TILE
     override); used to label bench.py's per-launch timings with the names rocprofv3 reports.  epi3: the launch has the compact
     bias + residual -> fp32 epilogue (proj / fc2 forward), which the forward layout runs on the phased kernel; epi1: the compact
     (bias ->) bf16 epilogue, phased too once the reduction is long (K >= 1536: the fc1 / qkv data gradients)."""
     if split_k > 1:
-        return "gemm_tn_stream_kernel" if int(tile256) == 2 else ("gemm256_kernel<split-K>" if tile256 else "gemm_kernel<split-K>")
+        if int(tile256) == 2:
+            return "gemm_tn_stream_kernel"
+        if tile256:
+            return "gemm_tn_stream256_kernel" if (not a_kmajor and not b_kmajor and STREAM256) else "gemm256_kernel<split-K>"
+        return "gemm_kernel<split-K>"
     big = M >= 1024 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
     if not big:
         return "gemm_kernel"

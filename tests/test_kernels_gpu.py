@@ -202,7 +202,8 @@ def test_gemm_wgrad_group(dev, det, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"SA_GEMM_TILE": "6"}, {"SA_GEMM_TILE": "8", "SA_GEMM_WGRAD_RING": "1"}, {"SA_GEMM_TILE": "1"},
-                                 {"SA_GEMM_TILE": "A", "SA_GEMM_WGRAD_PHASE": "1"}, {"SA_GEMM_TILE": "P"}])
+                                 {"SA_GEMM_TILE": "A", "SA_GEMM_WGRAD_PHASE": "1"}, {"SA_GEMM_TILE": "P"},
+                                 {"SA_GEMM_WGRAD_STREAM256": "0"}])
 def test_gemm_tile_modes(dev, env):
     """Large ragged problem through every tile variant of sa_gemm_bf16 (default dispatch first).  The variant is chosen by an
     environment variable the library reads once, hence one subprocess per variant (sequential: one GPU process at a time)."""
