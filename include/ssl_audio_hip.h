@@ -73,8 +73,8 @@ int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 int64_t sa_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int64_t sa_gemm_colsum_workspace_bytes(int32_t M, int32_t N);
 /* n <= 8 weight gradients over the SAME reduction in one pair of launches: out_f32_i[M_i, N_i] += alpha * A_i^T B_i for i < n (both
- * operands k-strided, the same K = number of rows, the same alpha and split_k > 1, tile256 = 2 semantics: the 192 x 192 streaming
- * kernel).  The four weight gradients of a transformer block (models/mae.py:106-129,149-163: qkv, proj, fc1, fc2 at backward) are
+ * operands k-strided, the same K = number of rows, the same alpha and split_k > 1; args[0].tile256 picks the streaming kernel for
+ * the whole group: 2 (or 0) = 192 x 192 tiles for narrow outputs, 1 = 256 x 256 tiles for wide ones).  The four weight gradients of a transformer block (models/mae.py:106-129,149-163: qkv, proj, fc1, fc2 at backward) are
  * such a group.  Why one launch: split-K costs one fp32 partial tile per WORKGROUP whatever the split, and a launch needs a
  * workgroup per CU to stream at the HBM rate -- four launches write and re-read four chips' worth of partials, a group one.
  * Every args[i] as for sa_gemm_bf16 with split_k > 1 (only A, B, lda, ldb, M, N, K, alpha, out_f32, ldo_f32, split_k, splitk_ws are

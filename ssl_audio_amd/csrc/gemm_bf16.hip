@@ -1320,7 +1320,8 @@ extern "C" int sa_gemm_wgrad_group(const SaGemmArgs* args, int32_t n, void* stre
     q.lda = (int)a->lda; q.ldb = (int)a->ldb; q.M = a->M; q.N = a->N;
     q.ws = a->splitk_ws; q.out = a->out_f32; q.ldo = a->ldo_f32;
   }
-  const int rc = sagemm::launch_stream_group(g, stream);
+  const int tile = args[0].tile256 == 1 ? 256 : 192;       // (tile256 of the first product: 1 = the 256 x 256 ring for wide outputs)
+  const int rc = sagemm::launch_stream_group(g, tile, stream);
   if (rc != 0 || !det) return rc;
   return sagemm::launch_stream_reduce(g, stream);
 }

@@ -68,7 +68,7 @@ struct StreamGroup {
   float alpha;
 };
 int launch_stream(GemmParams p, hipStream_t stream);
-int launch_stream_group(StreamGroup& g, hipStream_t stream);
+int launch_stream_group(StreamGroup& g, int tile /* 192 or 256 */, hipStream_t stream);
 int launch_stream_reduce(const StreamGroup& g, hipStream_t stream);
 int launch_stream256(GemmParams p, hipStream_t stream);
 // gemm_pair.hip: the 128 x 256 kernel with two workgroups per CU (both operands k-major, compact epilogue kinds 1/3/5/6/8); -1: not covered

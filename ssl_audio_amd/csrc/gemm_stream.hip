@@ -180,7 +180,7 @@ __device__ __forceinline__ int sw_frag_off(int sub, int lane) {
   return (sub >> 6) * SW_IMG + krow * 128 + (((col >> 4) ^ st_swz(krow)) << 5) + (col & 15) * 2;
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const sagemm::StreamGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -190,18 +190,21 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const GemmParams
   const int bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   const int lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int ks_id = lid / ntiles;
-  const int tile = lid - ks_id * ntiles;
-  const int GM = p.gm256;
-  const int group_sz = GM * p.tiles_n;
-  const int grp = tile / group_sz, within = tile - grp * group_sz;
-  const int gm = min(GM, p.tiles_m - grp * GM);
-  const int tm = grp * GM + within % gm, tn = within / gm;
+  // K slice slowest: the tiles of one slice (of every product of the group) run side by side and share their operand slabs in L2;
+  // inside a product the row tile runs fastest (a B column panel and all A panels of the slice: 12 slabs for 27 tiles at 2304 x 768)
+  const int ks_id = lid / grp.ntiles;
+  const int gtile = lid - ks_id * grp.ntiles;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < sagemm::STREAM_MAX_PROBLEMS; ++i)
+    if (i < grp.n && gtile >= grp.pr[i].tile0) pi = i;
+  const sagemm::StreamProb& p = grp.pr[pi];
+  const int tile = gtile - p.tile0;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
   const int m0 = tm * 256, n0 = tn * 256;
 
-  const int ksteps = (p.K + BK - 1) / BK;                    // slices are cut at the 64-row K-steps of the other split-K kernels
-  const int chunk = (ksteps + p.split_k - 1) / p.split_k;
+  const int ksteps = (grp.K + BK - 1) / BK;                  // slices are cut at the 64-row K-steps of the other split-K kernels
+  const int chunk = (ksteps + grp.split_k - 1) / grp.split_k;
   const int kt_begin = ks_id * chunk;
   const int nk = 2 * (min(ksteps, kt_begin + chunk) - kt_begin);     // 32-deep stages
   if (nk <= 0) return;
@@ -242,26 +245,21 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const GemmParams
   request(0, 0, true);
   request(1, 1, 1 < nk);
   request(2, 2, 2 < nk);
-  const bool late = (p.stagger & 8) && wr == 1;
-  const bool prio = (p.stagger & 16) != 0;
   int slot = 0, fill = 3;
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // stage t is in; stages t + 1 and t + 2 may still fly
     __syncthreads();
-    if (!late) request(fill, t + 3, t + 3 < nk);
+    request(fill, t + 3, t + 3 < nk);
     const char* st = smem + slot * SW_STAGE;
     bf16x8 fa[8], fb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[j] = st_frag(st, fb_off[j]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa[i] = st_frag(st, fa_off[i]);
-    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    if (prio) __builtin_amdgcn_s_setprio(0);
-    if (late) request(fill, t + 3, t + 3 < nk);              // (wave row 1: its share of the requests goes out behind its MFMAs)
     slot = slot == SW_NSTAGE - 1 ? 0 : slot + 1;
     fill = fill == SW_NSTAGE - 1 ? 0 : fill + 1;
   }
@@ -269,20 +267,25 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const GemmParams
 
   // ---- partials: lane owns row 16 i + c, columns 16 j + 4 g + [0, 4) of its 128 x 64 block
   const int g = lane >> 4, c = lane & 15;
+  const int M = p.M, N = p.N;
+  float* const ws = p.ws;
+  float* const out = p.out;
+  const int64_t ldo = p.ldo;
+  const float alpha = grp.alpha;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + 128 * wr + 16 * i + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + 64 * wc + 16 * j + 4 * g;
-      if (m < p.M && n < p.N) {
-        if (p.split_ws) {
-          *reinterpret_cast<float4*>(p.split_ws + ((int64_t)ks_id * p.M + m) * p.N + n) =
-              make_float4(p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]);
+      if (m < M && n < N) {
+        if (ws) {
+          *reinterpret_cast<float4*>(ws + ((int64_t)ks_id * M + m) * N + n) =
+              make_float4(alpha * acc[i][j][0], alpha * acc[i][j][1], alpha * acc[i][j][2], alpha * acc[i][j][3]);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) atomicAdd(p.out_f32 + (int64_t)m * p.ldo_f32 + n + r, p.alpha * acc[i][j][r]);
+            if (n + r < N) atomicAdd(out + (int64_t)m * ldo + n + r, alpha * acc[i][j][r]);
         }
       }
     }
@@ -339,12 +342,13 @@ __global__ __launch_bounds__(512) void stream_reduce_kernel(const sagemm::Stream
 
 }  // namespace
 
-// the 192 x 192 streaming kernel for `g.n` products that share the reduction (both operands k-strided, split_k > 1); fills in the tile
-// bookkeeping of `g`.  0 on success, 2 on a launch error
-int sagemm::launch_stream_group(StreamGroup& g, hipStream_t stream) {
+// the streaming kernel (tile = 192 or 256) for `g.n` products that share the reduction (both operands k-strided, split_k > 1); fills in
+// the tile bookkeeping of `g`.  0 on success, 2 on a launch error
+int sagemm::launch_stream_group(StreamGroup& g, int tile, hipStream_t stream) {
   static bool cfg = false;
   if (!cfg) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS) != hipSuccess) {
       sa_set_error("sa_gemm_bf16: 144 KiB of LDS per workgroup refused");
       return 2;
     }
@@ -353,15 +357,16 @@ int sagemm::launch_stream_group(StreamGroup& g, hipStream_t stream) {
   int tiles = 0, rblocks = 0;
   for (int i = 0; i < g.n; ++i) {
     StreamProb& q = g.pr[i];
-    q.tiles_m = (q.M + ST_TILE - 1) / ST_TILE;
+    q.tiles_m = (q.M + tile - 1) / tile;
     q.tile0 = tiles;
-    tiles += q.tiles_m * ((q.N + ST_TILE - 1) / ST_TILE);
+    tiles += q.tiles_m * ((q.N + tile - 1) / tile);
     q.rblock0 = rblocks;
     rblocks += (int)(((int64_t)q.M * (q.N / 4) + 63) / 64);
   }
   g.ntiles = tiles;
-  hipLaunchKernelGGL(gemm_tn_stream_kernel, dim3((unsigned)(tiles * g.split_k)), dim3(512), ST_LDS, stream, g);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(192 streaming split-K)");
+  if (tile == ST_TILE) hipLaunchKernelGGL(gemm_tn_stream_kernel, dim3((unsigned)(tiles * g.split_k)), dim3(512), ST_LDS, stream, g);
+  else hipLaunchKernelGGL(gemm_tn_stream256_kernel, dim3((unsigned)(tiles * g.split_k)), dim3(512), SW_LDS, stream, g);
+  SA_LAUNCH_CHECK("sa_gemm_bf16(streaming split-K)");
   return 0;
 }
 
@@ -376,28 +381,17 @@ int sagemm::launch_stream_reduce(const StreamGroup& g, hipStream_t stream) {
   return 0;
 }
 
-int sagemm::launch_stream(GemmParams p, hipStream_t stream) {
-  StreamGroup g = {};
+namespace {
+int launch_stream_single(const GemmParams& p, int tile, hipStream_t stream) {
+  sagemm::StreamGroup g = {};
   g.n = 1; g.K = p.K; g.split_k = p.split_k; g.alpha = p.alpha;
-  StreamProb& q = g.pr[0];
+  sagemm::StreamProb& q = g.pr[0];
   q.A = p.A; q.B = p.B; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N;
   q.ws = p.split_ws; q.out = p.out_f32; q.ldo = p.ldo_f32;
-  return launch_stream_group(g, stream);
+  return sagemm::launch_stream_group(g, tile, stream);
 }
+}  // namespace
 
-// the 256 x 256 form (both operands k-strided, split_k > 1); with a workspace N must be a multiple of 4 (float4 partial rows)
-int sagemm::launch_stream256(GemmParams p, hipStream_t stream) {
-  static bool cfg = false;
-  if (!cfg) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_stream256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS) != hipSuccess) {
-      sa_set_error("sa_gemm_bf16: 128 KiB of LDS per workgroup refused");
-      return 2;
-    }
-    cfg = true;
-  }
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  hipLaunchKernelGGL(gemm_tn_stream256_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split_k)), dim3(512), SW_LDS, stream, p);
-  SA_LAUNCH_CHECK("sa_gemm_bf16(256 streaming split-K)");
-  return 0;
-}
+int sagemm::launch_stream(GemmParams p, hipStream_t stream) { return launch_stream_single(p, ST_TILE, stream); }
+// the 256 x 256 form; with a workspace N must be a multiple of 4 (float4 partial rows)
+int sagemm::launch_stream256(GemmParams p, hipStream_t stream) { return launch_stream_single(p, 256, stream); }

@@ -232,6 +232,12 @@ def stream_wgrad(N, K, rows):
     return min(N, K) <= 192 if t192 <= 4 else min(N, K) <= 384
 
 
+def wide_wgrad(N, K, rows):
+    """The weight gradients that take the 256 x 256 split-K tile: measured (scripts/bench_gemm.py) with >= 9 output tiles of 256 x 256
+    (d = 768: every block weight) the one-workgroup-per-CU tile wins (halved operand traffic, the long reduction hides its epilogue)."""
+    return ((N + 255) // 256) * ((K + 255) // 256) >= WGRAD256_MIN_TILES and rows >= 4096
+
+
 def _wgrad(dY16, X16, out):
     """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip)."""
     N, K = out.shape
@@ -244,7 +250,7 @@ def _wgrad(dY16, X16, out):
         if split > 1:
             ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=2)
             return
-    if ((N + 255) // 256) * ((K + 255) // 256) >= WGRAD256_MIN_TILES and rows >= 4096:
+    if wide_wgrad(N, K, rows):
         split = ops.pick_split_k(N, K, rows, tile=256)
         if split > 1:
             ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=True)
@@ -257,6 +263,7 @@ def _wgrad(dY16, X16, out):
 
 
 WGRAD_GROUP = os.environ.get("SA_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP256 = os.environ.get("SA_WGRAD_GROUP256", "0") == "1"
 
 
 class WgradGroup:
@@ -264,28 +271,38 @@ class WgradGroup:
     (narrow outputs over the same rows: ViT-T's qkv / proj / fc1 / fc2, the MAE decoder's wide ones).  Split-K costs one fp32 partial
     tile per workgroup, and a launch wants a workgroup per CU: four launches write and re-read four chips' worth of partials (148 MB
     per ViT-T block against 784 MB of operands), one group launch a quarter of that (ops.gemm_wgrad_group).  Everything else goes out
-    at once through `_wgrad`.  The operands stay referenced until `flush()`."""
-    __slots__ = ("jobs",)
+    at once through `_wgrad`.  The operands stay referenced until `flush()`.
+    Wide outputs (d = 768 / 1024: the 256 x 256 ring) CAN be grouped the same way (SA_WGRAD_GROUP256=1: 27 + 9 + 36 + 36 tiles split 7
+    ways are 756 partial tiles instead of the 999 of four separately split launches) but measured slower -- ViT-B step 39.2 -> 40.0 ms:
+    756 workgroups are three unsynchronised rounds on 256 CUs, and the tiles of a K slice no longer run side by side to share their
+    operand slabs in L2 -- so they stay four launches of one round each."""
+    __slots__ = ("jobs", "tile")
 
     def __init__(self):
-        self.jobs = []
+        self.jobs, self.tile = [], 0
 
     def add(self, dY16, X16, out):
         N, K = out.shape
         rows = dY16.shape[0]
-        if WGRAD_GROUP and stream_wgrad(N, K, rows) and len(self.jobs) < 8 and (not self.jobs or self.jobs[0][0].shape[0] == rows):
+        tile = 0
+        if WGRAD_GROUP and stream_wgrad(N, K, rows):
+            tile = 192
+        elif WGRAD_GROUP256 and wide_wgrad(N, K, rows) and K % 4 == 0 and ops.STREAM256:
+            tile = 256
+        if tile and len(self.jobs) < 8 and (not self.jobs or (self.jobs[0][0].shape[0] == rows and self.tile == tile)):
             self.jobs.append((dY16, X16, out))
+            self.tile = tile
         else:
             _wgrad(dY16, X16, out)
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
         if len(jobs) > 1:
-            rows = jobs[0][0].shape[0]
-            tiles = sum(((o.shape[0] + 191) // 192) * ((o.shape[1] + 191) // 192) for _, _, o in jobs)
-            split = ops.pick_split_k(0, 0, rows, tile=192, tiles=tiles)
+            rows, t = jobs[0][0].shape[0], self.tile
+            tiles = sum(((o.shape[0] + t - 1) // t) * ((o.shape[1] + t - 1) // t) for _, _, o in jobs)
+            split = ops.pick_split_k(0, 0, rows, tile=t, tiles=tiles)
             if split > 1:
-                ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], split)
+                ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], split, tile=t)
                 return
         for j in jobs:
             _wgrad(*j)

@@ -166,10 +166,12 @@ def set_dynamic_tiles(on):
     check(lib().sa_set_dynamic_tiles(int(bool(on))), "sa_set_dynamic_tiles")
 
 
-def gemm_wgrad_group(dY, X, out, split_k):
+def gemm_wgrad_group(dY, X, out, split_k, tile=192):
     """dY[i] [rows, N_i] bf16, X[i] [rows, K_i] bf16, out[i] [N_i, K_i] fp32, all over the same rows: out_i += dY_i^T X_i for the whole
-    group in ONE pair of launches of the 192 x 192 streaming kernel (include/ssl_audio_hip.h: sa_gemm_wgrad_group) -- the four weight
-    gradients of a transformer block at backward (models/mae.py:106-129,149-163)."""
+    group in ONE pair of launches of the streaming split-K kernel (include/ssl_audio_hip.h: sa_gemm_wgrad_group; tile 192 for narrow
+    outputs, 256 for wide ones) -- the four weight gradients of a transformer block at backward (models/mae.py:106-129,149-163)."""
+    if tile not in (192, 256):
+        raise ValueError("gemm_wgrad_group: tile must be 192 or 256")
     jobs = list(zip(dY, X, out))
     n = len(jobs)
     arr = (SaGemmArgs * n)()
@@ -187,7 +189,7 @@ def gemm_wgrad_group(dY, X, out, split_k):
         a.B, a.ldb, a.b_kmajor = X.data_ptr(), ldb, 0
         a.M, a.N, a.K, a.alpha = M, N, rows, 1.0
         a.out_f32, a.ldo_f32 = out.data_ptr(), _rows(out, "out")[2]
-        a.split_k, a.tile256 = split_k, 2
+        a.split_k, a.tile256 = split_k, (2 if tile == 192 else 1)
         if det:
             a.splitk_ws = ws.data_ptr() + off
             off += (size + 255) // 256 * 256
@@ -200,7 +202,8 @@ def gemm_wgrad_group(dY, X, out, split_k):
     e0.record()
     check(lib().sa_gemm_wgrad_group(arr, n, _stream()), "sa_gemm_wgrad_group")
     e1.record()
-    GEMM_PROFILE.append((e0, e1, flops, "TN/splitk", nbytes, "gemm_tn_stream_kernel", f"gemm_tn_stream_kernel<group of {n}>"))
+    kname = "gemm_tn_stream_kernel" if tile == 192 else "gemm_tn_stream256_kernel"
+    GEMM_PROFILE.append((e0, e1, flops, "TN/splitk", nbytes, kname, f"{kname}<group of {n}>"))
 
 
 STREAM256 = os.environ.get("SA_GEMM_WGRAD_STREAM256", "1") != "0"      # (mirror of gemm_dispatch's default for TN split-K on the 256 tile)

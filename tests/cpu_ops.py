@@ -29,7 +29,7 @@ def pick_split_k(M, N, K, cu_count=None, tile=128, tiles=None):
     return 1
 
 
-def gemm_wgrad_group(dY, X, out, split_k):
+def gemm_wgrad_group(dY, X, out, split_k, tile=192):
     for dy, x, o in zip(dY, X, out):
         o += dy.float().t() @ x.float()
 
@@ -175,3 +175,4 @@ def bt_bwd_apply(z1n, z2n, rstd, dzn, sums, inv_n, out_scale, dz1, dz2):
     for v, (zn, dz) in enumerate(((z1n, dz1), (z2n, dz2))):
         d = rstd[v] * (dzn[v] - sums[v, 0] * inv_n - zn * sums[v, 1] * inv_n)
         dz.copy_(d * out_scale if out_scale is not None else d)
+STREAM256 = False

@@ -194,6 +194,18 @@ def test_gemm_wgrad_group(dev, det, monkeypatch):
             single = b.clone()
             ops.gemm(dy, x, a_kmajor=False, b_kmajor=False, out_f32=single, split_k=split, tile256=2)
             assert rel_err(o, single.double().cpu()) < 1e-6
+    # the same on the 256 x 256 ring (wide outputs: a ViT-B block's shapes at a short reduction, plus a ragged product)
+    d, rows, split = 768, 64 * 23 + 8, 5
+    ops_in = [(bf(rnd((rows, n), 70 + i)).to(dev), bf(rnd((rows, k), 80 + i)).to(dev)) for i, (n, k) in enumerate([(d, 4 * d), (4 * d, d), (d, d), (3 * d, d), (520, 304)])]
+    base = [torch.randn(dy.shape[1], x.shape[1], device=dev) for dy, x in ops_in]
+    outs = [b_.clone() for b_ in base]
+    ops.gemm_wgrad_group([j[0] for j in ops_in], [j[1] for j in ops_in], outs, split, tile=256)
+    for (dy, x), b_, o in zip(ops_in, base, outs):
+        assert rel_err(o, b_.double().cpu() + dy.double().cpu().T @ x.double().cpu()) < 1e-5, tuple(o.shape)
+        single = b_.clone()
+        ops.gemm(dy, x, a_kmajor=False, b_kmajor=False, out_f32=single, split_k=split, tile256=True)
+        assert rel_err(o, single.double().cpu()) < 1e-6
+    d = 192
     o = [torch.zeros(d, d, device=dev), torch.zeros(d, d, device=dev)]
     with pytest.raises((RuntimeError, ValueError), match="same in the whole group|do not form"):
         ops.gemm_wgrad_group([dx2, dx2[:320]], [ao, ao[:320]], o, 4)
