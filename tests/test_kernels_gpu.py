@@ -144,10 +144,10 @@ def test_gemm_split_k_deterministic(dev, tile256, monkeypatch):
         assert rel_err(out, outs[0].double().cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("N,K", [(576, 192), (192, 192), (768, 192), (192, 768), (200, 392), (64, 136)])
+@pytest.mark.parametrize("N,K", [(576, 192), (192, 192), (768, 192), (192, 768), (200, 392), (64, 136), (1152, 384), (384, 1536)])
 def test_gemm_streaming_narrow_wgrad(dev, N, K):
     """The 192 x 192 streaming split-K kernel (tile256 = 2; csrc/gemm_stream.hip) on ViT-T's four weight-gradient shapes (the products
-    of models/mae.py:106-129,149-163's Linear layers at d = 192) and on ragged outputs, against fp64 on the same bf16 operands: long
+    of models/mae.py:106-129,149-163's Linear layers at d = 192), two of the MAE decoder's (d = 384: 12 and 16 tiles) and on ragged outputs, against fp64 on the same bf16 operands: long
     slices (the three-stage ring wraps many times), one-K-step slices (only the prologue's requests are real), a short last slice, a
     reduction that is no multiple of 64 rows, and the split engine._wgrad picks at the full 127 488 rows."""
     for rows, split in [(127488 // 8, ops.pick_split_k(N, K, 127488 // 8, tile=192)), (64 * 7, 7), (64 * 9 + 17, 4), (64 * 40, 3)]:
