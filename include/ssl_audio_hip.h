@@ -68,6 +68,13 @@ typedef struct SaGemmArgs {
                                    out_f32 in slice order: the result is bit-reproducible from run to run (the atomic path is
                                    exact only up to the fp32 rounding of an arbitrary summation order).  Served by the two default
                                    split-K kernels (128 x 128 and tile256) */
+  float* asum_out;              /* optional, the streaming split-K kernels only (both operands k-strided, split_k > 1, tile256 = 2 or 1; also per
+                                   product of sa_gemm_wgrad_group): asum_out[m] += sum_k A[k][m] for m < M outside [asum_skip_lo, asum_skip_hi)
+                                   -- the BIAS gradient of the Linear whose weight gradient this product is (A = dY), taken from the dY tiles the
+                                   kernel has in LDS anyway instead of a second pass over dY (sa_colsum_bf16).  The skipped rows: the k third
+                                   of a packed qkv gradient, whose bias is fixed at zero (models/mae.py:125-128).  Other kernels refuse it. */
+  float* asum_ws;               /* scratch of split_k * M floats; required with splitk_ws (slice sums added in slice order), unused otherwise */
+  int32_t asum_skip_lo, asum_skip_hi;
 } SaGemmArgs;
 int sa_gemm_bf16(const SaGemmArgs* args_host, void* stream);
 int64_t sa_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t split_k);

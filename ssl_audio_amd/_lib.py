@@ -30,6 +30,7 @@ class SaGemmArgs(C.Structure):
         ("row_group", I32), ("split_k", I32), ("accumulate", I32), ("tile256", I32),
         ("colsum_out", P), ("colsum_ws", P),
         ("splitk_ws", P),
+        ("asum_out", P), ("asum_ws", P), ("asum_skip_lo", I32), ("asum_skip_hi", I32),
     ]
 
 

@@ -1160,6 +1160,15 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   p.colsum_ws = a->colsum_out ? a->colsum_ws : nullptr;
   p.split_ws = a->split_k > 1 ? a->splitk_ws : nullptr;
   p.tile_counter = nullptr;
+  p.asum_out = a->asum_out; p.asum_ws = a->asum_ws; p.asum_lo = a->asum_skip_lo; p.asum_hi = a->asum_skip_hi;
+  if (a->asum_out) {
+    static const char* ws256 = getenv("SA_GEMM_WGRAD_STREAM256");
+    const bool stream_path = a->split_k > 1 && !a->a_kmajor && !a->b_kmajor &&
+                             (a->tile256 == 2 || (a->tile256 == 1 && !(ws256 && ws256[0] == '0') && (!a->splitk_ws || a->N % 4 == 0)));
+    SA_CHECK_ARG(stream_path, "sa_gemm_bf16: asum_out is served by the streaming split-K kernels only (k-strided operands, split_k > 1, tile256 = 2 or 1)");
+    SA_CHECK_ARG((a->asum_ws != nullptr) == (a->splitk_ws != nullptr), "sa_gemm_bf16: asum_ws goes with splitk_ws (both or neither)");
+    SA_CHECK_ARG(a->asum_skip_lo >= 0 && a->asum_skip_hi >= a->asum_skip_lo, "sa_gemm_bf16: bad asum_skip range");
+  }
   static const char* es_env = getenv("SA_GEMM_EPI_COMPACT");
   p.epi_kind = 0;
   {
@@ -1319,6 +1328,10 @@ extern "C" int sa_gemm_wgrad_group(const SaGemmArgs* args, int32_t n, void* stre
     q.b_bytes = (uint32_t)((((int64_t)a->K - 1) * a->ldb + a->N) * 2);
     q.lda = (int)a->lda; q.ldb = (int)a->ldb; q.M = a->M; q.N = a->N;
     q.ws = a->splitk_ws; q.out = a->out_f32; q.ldo = a->ldo_f32;
+    q.asum_out = a->asum_out; q.asum_ws = a->asum_ws; q.asum_lo = a->asum_skip_lo; q.asum_hi = a->asum_skip_hi;
+    if (a->asum_out)
+      SA_CHECK_ARG((a->asum_ws != nullptr) == det && a->asum_skip_lo >= 0 && a->asum_skip_hi >= a->asum_skip_lo,
+                   "sa_gemm_wgrad_group: product %d: asum_ws goes with splitk_ws, and the skip range must be ordered", i);
   }
   const int tile = args[0].tile256 == 1 ? 256 : 192;       // (tile256 of the first product: 1 = the 256 x 256 ring for wide outputs)
   const int rc = sagemm::launch_stream_group(g, tile, stream);

@@ -39,6 +39,7 @@ struct GemmParams {
   int epi_kind;      // 1..4: one of the compact epilogues applies (wave_epilogue_compact); 0: general epilogue
   int nt_store;      // bf16 outputs with non-temporal stores
   float* colsum_ws;  // [ceil(M/64)][N] partial column sums of the fp32 epilogue result (bias gradient of the producing Linear), or null
+  float* asum_out; float* asum_ws; int asum_lo, asum_hi;   // streaming split-K kernels: column sums of A (see StreamProb)
   int* tile_counter; // dynamic tile hand-out of the persistent kernels: a zeroed device word; workgroup b starts on tile b and draws every
                      // later tile as gridDim.x + atomicAdd(tile_counter, 1).  null: static striding (tile b, b + grid, ...)
 };
@@ -61,6 +62,9 @@ struct StreamProb {
   uint32_t a_bytes, b_bytes;
   int lda, ldb, M, N;
   int tile0, tiles_m, rblock0;     // filled by launch_stream_group: first tile / first reduce block of this product
+  float* asum_out; float* asum_ws; // optional: asum_out[m] += sum_k A[k][m] (bias gradient), partials [split_k][M] in the workspace form
+  int asum_lo, asum_hi;            // rows [asum_lo, asum_hi) are left alone
+  int ablock0;                     // filled by launch_stream_group: first reduce block of the row sums (512 rows per block)
 };
 struct StreamGroup {
   StreamProb pr[STREAM_MAX_PROBLEMS];

@@ -112,6 +112,13 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const sagemm::Strea
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // column sums of A (the bias gradient: StreamProb::asum_out) ride along as one more B fragment of ONES: the waves of column half 0 of the
+  // tiles of output column 0 add three MFMAs per 18; every column of the result holds sum_k A[k][m]
+  const bool do_asum = p.asum_out != nullptr && tn == 0 && wn == 0;
+  f32x4 asum[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) asum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
   request(0, kt_begin, true);
   request(1, kt_begin + 1, 1 < nk);
@@ -132,6 +139,10 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const sagemm::Strea
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, asum[i], 0, 0, 0);
+      }
     }
     slot = slot == ST_NSTAGE - 1 ? 0 : slot + 1;
     fill = fill == ST_NSTAGE - 1 ? 0 : fill + 1;
@@ -159,6 +170,21 @@ __global__ __launch_bounds__(512) void gemm_tn_stream_kernel(const sagemm::Strea
         }
       }
     }
+  if (do_asum && c == 0) {                                   // (column 0 of the ones product: lanes c = 0 hold rows 4 g + r)
+    float* const aws = p.asum_ws;
+    float* const aout = p.asum_out;
+    const int lo = p.asum_lo, hi = p.asum_hi;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 48 * wm + 16 * i + 4 * g + r;
+        if (m < M && (m < lo || m >= hi)) {
+          if (aws) aws[(int64_t)ks_id * M + m] = alpha * asum[i][r];
+          else atomicAdd(aout + m, alpha * asum[i][r]);
+        }
+      }
+  }
 }
 
 // =====================================================================================================
@@ -241,6 +267,12 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const sagemm::St
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // column sums of A through a B fragment of ones, as in the 192 kernel (wave column 0 of the tiles of output column 0: 8 MFMAs per 32)
+  const bool do_asum = p.asum_out != nullptr && tn == 0 && wc == 0;
+  f32x4 asum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
 
   request(0, 0, true);
   request(1, 1, 1 < nk);
@@ -260,6 +292,10 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const sagemm::St
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    if (do_asum) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], asum[i], 0, 0, 0);
+    }
     slot = slot == SW_NSTAGE - 1 ? 0 : slot + 1;
     fill = fill == SW_NSTAGE - 1 ? 0 : fill + 1;
   }
@@ -290,15 +326,43 @@ __global__ __launch_bounds__(512) void gemm_tn_stream256_kernel(const sagemm::St
       }
     }
   }
+  if (do_asum && g == 0) {                                   // (swapped operands: every column of row 16 i + c holds the sum; lanes g = 0 store it)
+    float* const aws = p.asum_ws;
+    float* const aout = p.asum_out;
+    const int lo = p.asum_lo, hi = p.asum_hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + 128 * wr + 16 * i + c;
+      if (m < M && (m < lo || m >= hi)) {
+        if (aws) aws[(int64_t)ks_id * M + m] = alpha * asum[i][0];
+        else atomicAdd(aout + m, alpha * asum[i][0]);
+      }
+    }
+  }
 }
 
 // deterministic split-K, second launch, for a whole group: out_i[m][n] += sum over slices (in slice order) of ws_i[s][m][n].  One
 // block = 64 float4 columns of one product (blocks are dealt to the products in order); its eight waves take every eighth slice, their
 // partial sums meet in LDS and are added in wave order (sa_gemm_bf16's splitk_reduce_wide_kernel, with a product table in front).
-__global__ __launch_bounds__(512) void stream_reduce_kernel(const sagemm::StreamGroup grp, int nslice) {
+__global__ __launch_bounds__(512) void stream_reduce_kernel(const sagemm::StreamGroup grp, int nslice, int rblocks) {
   constexpr int NW = 8;
   __shared__ float4 part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= rblocks) {                          // the blocks behind the matrices: asum_out[m] += slice sums, 512 rows per block
+    const int ab = (int)blockIdx.x - rblocks;
+    int qi = -1;
+#pragma unroll
+    for (int i = 0; i < sagemm::STREAM_MAX_PROBLEMS; ++i)
+      if (i < grp.n && grp.pr[i].ablock0 >= 0 && ab >= grp.pr[i].ablock0) qi = i;
+    if (qi < 0) return;
+    const sagemm::StreamProb& q = grp.pr[qi];
+    const int m = (ab - q.ablock0) * 512 + (int)threadIdx.x;
+    if (m >= q.M || (m >= q.asum_lo && m < q.asum_hi)) return;
+    float s = 0.f;
+    for (int sl = 0; sl < nslice; ++sl) s += q.asum_ws[(int64_t)sl * q.M + m];
+    q.asum_out[m] += s;
+    return;
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < sagemm::STREAM_MAX_PROBLEMS; ++i)
@@ -354,7 +418,7 @@ int sagemm::launch_stream_group(StreamGroup& g, int tile, hipStream_t stream) {
     }
     cfg = true;
   }
-  int tiles = 0, rblocks = 0;
+  int tiles = 0, rblocks = 0, ablocks = 0;
   for (int i = 0; i < g.n; ++i) {
     StreamProb& q = g.pr[i];
     q.tiles_m = (q.M + tile - 1) / tile;
@@ -362,6 +426,8 @@ int sagemm::launch_stream_group(StreamGroup& g, int tile, hipStream_t stream) {
     tiles += q.tiles_m * ((q.N + tile - 1) / tile);
     q.rblock0 = rblocks;
     rblocks += (int)(((int64_t)q.M * (q.N / 4) + 63) / 64);
+    q.ablock0 = (q.asum_out && q.asum_ws) ? ablocks : -1;
+    if (q.ablock0 >= 0) ablocks += (q.M + 511) / 512;
   }
   g.ntiles = tiles;
   if (tile == ST_TILE) hipLaunchKernelGGL(gemm_tn_stream_kernel, dim3((unsigned)(tiles * g.split_k)), dim3(512), ST_LDS, stream, g);
@@ -376,7 +442,10 @@ int sagemm::launch_stream_reduce(const StreamGroup& g, hipStream_t stream) {
   const int nslice = (ksteps + chunk - 1) / chunk;           // trailing slices with an empty K range wrote nothing
   const StreamProb& last = g.pr[g.n - 1];
   const int rblocks = last.rblock0 + (int)(((int64_t)last.M * (last.N / 4) + 63) / 64);
-  hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)rblocks), dim3(512), 0, stream, g, nslice);
+  int ablocks = 0;
+  for (int i = 0; i < g.n; ++i)
+    if (g.pr[i].ablock0 >= 0) ablocks = g.pr[i].ablock0 + (g.pr[i].M + 511) / 512;
+  hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)(rblocks + ablocks)), dim3(512), 0, stream, g, nslice, rblocks);
   SA_LAUNCH_CHECK("sa_gemm_wgrad_group(split-K reduce)");
   return 0;
 }
@@ -388,7 +457,16 @@ int launch_stream_single(const GemmParams& p, int tile, hipStream_t stream) {
   sagemm::StreamProb& q = g.pr[0];
   q.A = p.A; q.B = p.B; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.lda = p.lda; q.ldb = p.ldb; q.M = p.M; q.N = p.N;
   q.ws = p.split_ws; q.out = p.out_f32; q.ldo = p.ldo_f32;
-  return sagemm::launch_stream_group(g, tile, stream);
+  q.asum_out = p.asum_out; q.asum_ws = p.asum_ws; q.asum_lo = p.asum_lo; q.asum_hi = p.asum_hi;
+  const int rc = sagemm::launch_stream_group(g, tile, stream);
+  // (a single product's matrix partials are summed by sa_gemm_bf16's reduce launch; its row sums need this one)
+  if (rc == 0 && q.asum_out && q.asum_ws) {
+    const int ksteps = (g.K + BK - 1) / BK, chunk = (ksteps + g.split_k - 1) / g.split_k;
+    const int nslice = (ksteps + chunk - 1) / chunk;
+    hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)((q.M + 511) / 512)), dim3(512), 0, stream, g, nslice, 0);
+    SA_LAUNCH_CHECK("sa_gemm_bf16(row-sum reduce)");
+  }
+  return rc;
 }
 }  // namespace
 

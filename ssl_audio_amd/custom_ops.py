@@ -24,8 +24,9 @@ SCHEMAS = {
     "gemm": ("sa_gemm_bf16", "(Tensor A, Tensor B, *, bool a_kmajor=True, bool b_kmajor=True, float alpha=1.0, Tensor? bias=None, int act=0, "
              "Tensor? aux_in=None, Tensor(a!)? aux_out=None, Tensor? residual=None, int res_mod=0, Tensor(b!)? out_f32=None, "
              "Tensor(c!)? out_bf16=None, int row_group=0, int split_k=1, bool accumulate=False, bool tile256=False, "
-             "Tensor(d!)? colsum_out=None) -> ()"),
-    "gemm_wgrad_group": ("sa_gemm_wgrad_group", "(Tensor[] dY, Tensor[] X, Tensor(a!)[] out, int split_k, int tile=192) -> ()"),
+             "Tensor(d!)? colsum_out=None, Tensor(e!)? asum_out=None, int asum_skip_lo=0, int asum_skip_hi=0) -> ()"),
+    "gemm_wgrad_group": ("sa_gemm_wgrad_group", "(Tensor[] dY, Tensor[] X, Tensor(a!)[] out, int split_k, int tile=192, Tensor(b!)? asum_out=None, int asum_index=-1, "
+                         "int asum_skip_lo=0, int asum_skip_hi=0) -> ()"),
     "transpose_bf16": ("sa_transpose_bf16", "(Tensor src, Tensor(a!) dst) -> ()"),
     # (the matrices written are named by pointers inside `desc`; the schema marks desc so that the operator counts as one with a side effect)
     "transpose_bf16_batch": ("sa_transpose_bf16_batch", "(Tensor(a!) desc, int n_tiles) -> ()"),

@@ -238,28 +238,63 @@ def wide_wgrad(N, K, rows):
     return ((N + 255) // 256) * ((K + 255) // 256) >= WGRAD256_MIN_TILES and rows >= 4096
 
 
-def _wgrad(dY16, X16, out):
-    """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip)."""
+ASUM_FUSE = os.environ.get("SA_WGRAD_BIAS_FUSE", "1") != "0"
+
+
+class RowSums:
+    """A bias gradient that may ride along with its Linear's weight-gradient launch: `out` [>= N] fp32 gets += the column sums of dY outside
+    rows [skip_lo, skip_hi) when the product runs on a streaming split-K kernel (ops.gemm(asum_out=)); `fallback()` does the same as a
+    pass of its own (ops.colsum_*) when it does not."""
+    __slots__ = ("out", "skip_lo", "skip_hi", "fallback")
+
+    def __init__(self, out, skip_lo, skip_hi, fallback):
+        self.out, self.skip_lo, self.skip_hi, self.fallback = out, skip_lo, skip_hi, fallback
+
+
+def qv_row_sums(dqkv, d, gq, gv):
+    """The q / v bias gradient of a packed qkv Linear (models/mae.py:125-128; k's bias is fixed at zero) as a RowSums: fusable when the two
+    buffers sit 2 d apart in one allocation (train.FlatState's [q | 0 | v] layout), so that one [3 d] vector with the k third skipped
+    covers both."""
+    fb = lambda: ops.colsum_qv(dqkv, d, gq, gv)
+    if ASUM_FUSE and gv.data_ptr() == gq.data_ptr() + 8 * d and gq.is_contiguous() and gv.is_contiguous() and gq.dtype == torch.float32:
+        return RowSums(gq.view(-1).as_strided((3 * d,), (1,)), d, 2 * d, fb)
+    return RowSums(None, 0, 0, fb)
+
+
+def _wgrad(dY16, X16, out, rs=None):
+    """out[N,K] += dY^T X  (TN GEMM; split-K atomics when the output has too few tiles to fill the chip).  rs: an optional RowSums (the
+    Linear's bias gradient): fused into the launch on the streaming kernels, else taken by its fallback."""
     N, K = out.shape
     rows = dY16.shape[0]
+    kw = {}
+    if rs is not None and rs.out is not None:
+        kw = dict(asum_out=rs.out, asum_skip_lo=rs.skip_lo, asum_skip_hi=rs.skip_hi)
     # measured (scripts/bench_gemm.py): with >= 9 output tiles of 256 x 256 (d = 768: every block weight) the one-workgroup-per-CU
     # 256^2 split-K tile wins (halved operand traffic, the long reduction hides its epilogue; proj at 9 tiles x 28 slices: 102 vs
     # 110 us); narrower outputs (ViT-T) stay on the 128^2 tile
     if stream_wgrad(N, K, rows):
         split = ops.pick_split_k(N, K, rows, tile=192)
         if split > 1:
-            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=2)
+            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=2, **kw)
+            if rs is not None and not kw:
+                rs.fallback()
             return
     if wide_wgrad(N, K, rows):
         split = ops.pick_split_k(N, K, rows, tile=256)
         if split > 1:
-            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=True)
+            if not (ops.STREAM256 and K % 4 == 0):       # (the two-stage kernel has no row sums)
+                kw = {}
+            ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split, tile256=True, **kw)
+            if rs is not None and not kw:
+                rs.fallback()
             return
     split = ops.pick_split_k(N, K, rows)
     if split > 1:
         ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, split_k=split)
     else:
         ops.gemm(dY16, X16, a_kmajor=False, b_kmajor=False, out_f32=out, accumulate=True)
+    if rs is not None:
+        rs.fallback()
 
 
 WGRAD_GROUP = os.environ.get("SA_WGRAD_GROUP", "1") != "0"
@@ -276,12 +311,12 @@ class WgradGroup:
     ways are 756 partial tiles instead of the 999 of four separately split launches) but measured slower -- ViT-B step 39.2 -> 40.0 ms:
     756 workgroups are three unsynchronised rounds on 256 CUs, and the tiles of a K slice no longer run side by side to share their
     operand slabs in L2 -- so they stay four launches of one round each."""
-    __slots__ = ("jobs", "tile")
+    __slots__ = ("jobs", "tile")          # jobs: (dY, X, out, RowSums or None)
 
     def __init__(self):
         self.jobs, self.tile = [], 0
 
-    def add(self, dY16, X16, out):
+    def add(self, dY16, X16, out, rs=None):
         N, K = out.shape
         rows = dY16.shape[0]
         tile = 0
@@ -290,19 +325,26 @@ class WgradGroup:
         elif WGRAD_GROUP256 and wide_wgrad(N, K, rows) and K % 4 == 0 and ops.STREAM256:
             tile = 256
         if tile and len(self.jobs) < 8 and (not self.jobs or (self.jobs[0][0].shape[0] == rows and self.tile == tile)):
-            self.jobs.append((dY16, X16, out))
+            self.jobs.append((dY16, X16, out, rs))
             self.tile = tile
         else:
-            _wgrad(dY16, X16, out)
+            _wgrad(dY16, X16, out, rs)
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
         if len(jobs) > 1:
             rows, t = jobs[0][0].shape[0], self.tile
-            tiles = sum(((o.shape[0] + t - 1) // t) * ((o.shape[1] + t - 1) // t) for _, _, o in jobs)
+            tiles = sum(((o.shape[0] + t - 1) // t) * ((o.shape[1] + t - 1) // t) for _, _, o, _ in jobs)
             split = ops.pick_split_k(0, 0, rows, tile=t, tiles=tiles)
             if split > 1:
-                ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], split, tile=t)
+                kw, fused = {}, None
+                for i, j in enumerate(jobs):              # (one product of a group may carry its bias gradient: the qkv Linear's)
+                    if j[3] is not None and j[3].out is not None and fused is None:
+                        fused, kw = i, dict(asum_out=j[3].out, asum_index=i, asum_skip_lo=j[3].skip_lo, asum_skip_hi=j[3].skip_hi)
+                ops.gemm_wgrad_group([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], split, tile=t, **kw)
+                for i, j in enumerate(jobs):
+                    if j[3] is not None and i != fused:
+                        j[3].fallback()
                 return
         for j in jobs:
             _wgrad(*j)
@@ -389,9 +431,8 @@ def block_backward(dx3, dx3_16, p, g, H, N, saved, b2_done=False, prev_b2=None):
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv)
     # qkv
-    wg.add(dqkv, h1, g.wqkv)
+    wg.add(dqkv, h1, g.wqkv, qv_row_sums(dqkv, d, g.qb, g.vb))       # (the q / v bias gradient rides along where the kernel allows)
     wg.flush()
-    ops.colsum_qv(dqkv, d, g.qb, g.vb)
     dh1 = dao
     wqb, wqk = _dgrad_w(p.wqkv)
     ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)
@@ -465,8 +506,7 @@ def block_backward_cls(dx3, dx3_16, p, g, H, N, saved, prev_b2=None):
     ops.gemm(dx2_16, W(p.wp), b_kmajor=False, out_bf16=dao.view(S, N * d)[:, :d])
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, H, N, (d // H) ** -0.5, ao, dao, lse, dqkv, n_query=1)
-    _wgrad(dqkv, h1, g.wqkv)
-    ops.colsum_qv(dqkv, d, g.qb, g.vb)
+    _wgrad(dqkv, h1, g.wqkv, qv_row_sums(dqkv, d, g.qb, g.vb))
     dh1 = dao
     wqb, wqk = _dgrad_w(p.wqkv)
     ops.gemm(dqkv, wqb, b_kmajor=wqk, out_bf16=dh1)

@@ -61,8 +61,11 @@ def _rows(t, name):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None,
-         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False, tile256=False, colsum_out=None):
-    """D = epilogue(alpha * A.B).  A: [M,K] (a_kmajor) or [K,M]; B: [N,K] (b_kmajor, nn.Linear weight) or [K,N]."""
+         res_mod=0, out_f32=None, out_bf16=None, row_group=0, split_k=1, accumulate=False, tile256=False, colsum_out=None,
+         asum_out=None, asum_skip_lo=0, asum_skip_hi=0):
+    """D = epilogue(alpha * A.B).  A: [M,K] (a_kmajor) or [K,M]; B: [N,K] (b_kmajor, nn.Linear weight) or [K,N].
+    asum_out (streaming split-K weight gradients only): [M] fp32, += sum_k A[k][m] outside rows [asum_skip_lo, asum_skip_hi) -- the bias
+    gradient of the Linear, out of the dY tiles the kernel holds anyway."""
     _req(A, BF16, "A"), _req(B, BF16, "B")
     ar, ac, lda = _rows(A, "A")
     br, bc, ldb = _rows(B, "B")
@@ -96,6 +99,12 @@ def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux
             import warnings
             warnings.warn(f"sa_gemm_bf16: split-K output with N = {N} (not a multiple of 4) falls back to fp32 atomics: this weight "
                           "gradient is summed in a run-dependent order (reproducible to fp32 rounding, not bit for bit)")
+    if asum_out is not None:
+        a.asum_out, a.asum_skip_lo, a.asum_skip_hi = _req(asum_out, F32, "asum_out").data_ptr(), int(asum_skip_lo), int(asum_skip_hi)
+        if asum_out.numel() < M or not asum_out.is_contiguous():
+            raise ValueError("gemm: asum_out must be a contiguous fp32 vector of at least M elements")
+        if a.splitk_ws:
+            a.asum_ws = _workspace(4 * split_k * M, A.device, "gemm_asum").data_ptr()
     if colsum_out is not None:          # colsum_out[n] += sum_m (fp32 epilogue result)[m][n], through a scratch of per-64-row partials
         ws = _workspace(lib().sa_gemm_colsum_workspace_bytes(M, N), A.device, "gemm_colsum")
         a.colsum_out, a.colsum_ws = _req(colsum_out, F32, "colsum_out").data_ptr(), ws.data_ptr()
@@ -166,12 +175,14 @@ def set_dynamic_tiles(on):
     check(lib().sa_set_dynamic_tiles(int(bool(on))), "sa_set_dynamic_tiles")
 
 
-def gemm_wgrad_group(dY, X, out, split_k, tile=192):
+def gemm_wgrad_group(dY, X, out, split_k, tile=192, asum_out=None, asum_index=-1, asum_skip_lo=0, asum_skip_hi=0):
     """dY[i] [rows, N_i] bf16, X[i] [rows, K_i] bf16, out[i] [N_i, K_i] fp32, all over the same rows: out_i += dY_i^T X_i for the whole
     group in ONE pair of launches of the streaming split-K kernel (include/ssl_audio_hip.h: sa_gemm_wgrad_group; tile 192 for narrow
     outputs, 256 for wide ones) -- the four weight gradients of a transformer block at backward (models/mae.py:106-129,149-163)."""
     if tile not in (192, 256):
         raise ValueError("gemm_wgrad_group: tile must be 192 or 256")
+    if asum_out is not None and not 0 <= asum_index < len(dY):
+        raise ValueError("gemm_wgrad_group: asum_index must name the product whose dY column sums go to asum_out")
     jobs = list(zip(dY, X, out))
     n = len(jobs)
     arr = (SaGemmArgs * n)()
@@ -180,7 +191,7 @@ def gemm_wgrad_group(dY, X, out, split_k, tile=192):
     det = DETERMINISTIC_WGRAD and all(X.shape[1] % 4 == 0 for _, X, _ in jobs)
     ws = _workspace(sum((s + 255) // 256 * 256 for s in sizes), jobs[0][0].device, "gemm_splitk_group") if det else None
     off, flops, nbytes = 0, 0.0, 0.0
-    for a, (dY, X, out), size in zip(arr, jobs, sizes):
+    for idx, (a, (dY, X, out), size) in enumerate(zip(arr, jobs, sizes)):
         _req(dY, BF16, "dY"), _req(X, BF16, "X"), _req(out, F32, "out")
         (ra, M, lda), (rb, N, ldb) = _rows(dY, "dY"), _rows(X, "X")
         if ra != rows or rb != rows or tuple(out.shape) != (M, N):
@@ -193,6 +204,13 @@ def gemm_wgrad_group(dY, X, out, split_k, tile=192):
         if det:
             a.splitk_ws = ws.data_ptr() + off
             off += (size + 255) // 256 * 256
+        if asum_out is not None and idx == asum_index:
+            # (product asum_index also leaves asum_out[m] += sum_rows dY[row][m] outside [asum_skip_lo, asum_skip_hi): its Linear's bias gradient)
+            if _req(asum_out, F32, "asum_out").numel() < M or not asum_out.is_contiguous():
+                raise ValueError("gemm_wgrad_group: asum_out must be a contiguous fp32 vector of at least M elements")
+            a.asum_out, a.asum_skip_lo, a.asum_skip_hi = asum_out.data_ptr(), int(asum_skip_lo), int(asum_skip_hi)
+            if det:
+                a.asum_ws = _workspace(4 * split_k * M, dY.device, "gemm_asum").data_ptr()
         flops += 2.0 * M * N * rows
         nbytes += 2.0 * (M + N) * rows + 4.0 * M * N
     if GEMM_PROFILE is None:

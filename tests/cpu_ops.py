@@ -29,9 +29,13 @@ def pick_split_k(M, N, K, cu_count=None, tile=128, tiles=None):
     return 1
 
 
-def gemm_wgrad_group(dY, X, out, split_k, tile=192):
+def gemm_wgrad_group(dY, X, out, split_k, tile=192, asum_out=None, asum_index=-1, asum_skip_lo=0, asum_skip_hi=0):
     for dy, x, o in zip(dY, X, out):
         o += dy.float().t() @ x.float()
+    if asum_out is not None:
+        s = dY[asum_index].float().sum(0)
+        s[asum_skip_lo:asum_skip_hi] = 0
+        asum_out[:s.numel()] += s
 
 
 def gemm(A, B, *, a_kmajor=True, b_kmajor=True, alpha=1.0, bias=None, act=0, aux_in=None, aux_out=None, residual=None, res_mod=0,

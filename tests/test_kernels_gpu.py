@@ -166,6 +166,42 @@ def test_gemm_streaming_narrow_wgrad(dev, N, K):
 
 
 @pytest.mark.parametrize("det", [True, False])
+def test_gemm_wgrad_bias_gradient_rides_along(dev, det, monkeypatch):
+    """asum_out of the streaming split-K kernels: the q / v bias gradient of a packed qkv Linear (models/mae.py:125-128: column sums of dqkv,
+    k's third skipped because its bias is fixed at zero) taken from the dY tiles of the weight-gradient launch -- 192 x 192 tiles (ViT-T),
+    256 x 256 tiles (ViT-B), as a single product and inside a block's group; against fp64 column sums, the skipped rows untouched, the weight
+    gradient itself unchanged by the extra fragment, the workspace form bit-reproducible; other kernels refuse the argument."""
+    monkeypatch.setattr(ops, "DETERMINISTIC_WGRAD", det)
+    for d, tile256, rows, split in [(192, 2, 64 * 83 + 24, 21), (768, 1, 64 * 40, 5)]:
+        dqkv, h1 = bf(rnd((rows, 3 * d), 51)).to(dev), bf(rnd((rows, d), 52)).to(dev)
+        ref = dqkv.double().cpu().sum(0)
+        runs = []
+        for _ in range(2):
+            w, b = torch.zeros(3 * d, d, device=dev), torch.full((3 * d,), 0.25, device=dev)
+            ops.gemm(dqkv, h1, a_kmajor=False, b_kmajor=False, out_f32=w, split_k=split, tile256=tile256, asum_out=b, asum_skip_lo=d, asum_skip_hi=2 * d)
+            runs.append((w, b))
+        w, b = runs[0]
+        assert float((b[d:2 * d] - 0.25).abs().max()) == 0.0
+        got = (b - 0.25).double().cpu()
+        for lo, hi in [(0, d), (2 * d, 3 * d)]:
+            assert float((got[lo:hi] - ref[lo:hi]).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-3
+        w0 = torch.zeros_like(w)
+        ops.gemm(dqkv, h1, a_kmajor=False, b_kmajor=False, out_f32=w0, split_k=split, tile256=tile256)
+        assert torch.equal(w, w0) if det else rel_err(w, w0.double().cpu()) < 1e-6
+        if det:
+            assert torch.equal(runs[0][1], runs[1][1])
+        # inside a group (the block's four products; the row sums belong to product 3)
+        x2 = bf(rnd((rows, d), 53)).to(dev)
+        outs = [torch.zeros(d, d, device=dev), torch.zeros(3 * d, d, device=dev)]
+        bg = torch.zeros(3 * d, device=dev)
+        ops.gemm_wgrad_group([x2, dqkv], [h1, h1], outs, split, tile=192 if tile256 == 2 else 256, asum_out=bg, asum_index=1, asum_skip_lo=d, asum_skip_hi=2 * d)
+        assert rel_err(outs[1], w0.double().cpu()) < 1e-6 and float(bg[d:2 * d].abs().max()) == 0.0
+        assert float((bg.double().cpu() - got).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-3
+    with pytest.raises(RuntimeError, match="streaming split-K kernels only"):
+        ops.gemm(dqkv, h1, a_kmajor=False, b_kmajor=False, out_f32=torch.zeros(3 * d, d, device=dev), split_k=4, asum_out=torch.zeros(3 * d, device=dev))
+
+
+@pytest.mark.parametrize("det", [True, False])
 def test_gemm_wgrad_group(dev, det, monkeypatch):
     """sa_gemm_wgrad_group: the four weight gradients of a ViT-T block (models/mae.py:106-129,149-163 at backward: qkv 576 x 192, proj
     192 x 192, fc1 768 x 192, fc2 192 x 768) over the same rows in ONE pair of launches, accumulated into non-zero buffers: against fp64
