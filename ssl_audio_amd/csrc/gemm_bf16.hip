@@ -1225,6 +1225,15 @@ int gemm_dispatch(const SaGemmArgs* a, hipStream_t stream) {
   // ... and on narrow outputs (one column tile: N <= 256) from K = 512 on: ViT-T's fc1 / qkv data gradients 59 -> 51 us, 43 -> 41 us
   const bool nt_phase = a->a_kmajor && a->b_kmajor && a->K >= 2 * BK &&
                         (p.epi_kind == 3 || (p.epi_kind == 1 && k1_min > 0 && (a->K >= k1_min || (a->N <= 256 && a->K >= 512))));
+  // thin reductions (K = 192: ViT-T) can stream through the weights-in-registers kernel (gemm_wreg.hip).  OPT-IN (SA_GEMM_WREG=1; 2 = and fail
+  // when a K = 192 forward-layout launch is not covered, for the parity test): built in round 5, parity-green, measured equal or slower
+  // than the tiled kernels on every ViT-T shape
+  static const char* wreg_env = getenv("SA_GEMM_WREG");
+  if (!force && wreg_env && (wreg_env[0] == '1' || wreg_env[0] == '2') && a->split_k == 1 && a->a_kmajor && a->b_kmajor && a->K == 192 && a->M >= 4096) {
+    const int rc = p.epi_kind != 0 ? sagemm::launch_wreg(p, stream) : -1;
+    if (rc >= 0) return rc;
+    SA_CHECK_ARG(wreg_env[0] != '2', "sa_gemm_bf16: SA_GEMM_WREG=2 and this K = 192 launch is not covered by the weights-in-registers kernel (N=%d, epilogue kind %d)", a->N, p.epi_kind);
+  }
   char mode = force ? force[0] : (big ? ((a->a_kmajor && !a->b_kmajor) ? '8' : (nt_phase ? 'A' : '6')) : '1');
   // mode P (gemm_pair.hip): 128 x 256 tiles, two 4-wave workgroups per CU -- one's epilogue under the other's main loop
   static const char* pair_env = getenv("SA_GEMM_PAIR");        // experiment knob: list of epilogue kinds that take mode P, e.g. "36"

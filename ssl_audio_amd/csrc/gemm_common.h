@@ -77,6 +77,9 @@ int launch_stream_reduce(const StreamGroup& g, hipStream_t stream);
 int launch_stream256(GemmParams p, hipStream_t stream);
 // gemm_pair.hip: the 128 x 256 kernel with two workgroups per CU (both operands k-major, compact epilogue kinds 1/3/5/6/8); -1: not covered
 int launch_pair(GemmParams p, hipStream_t stream);
+// gemm_wreg.hip: the weights-in-registers streaming kernel for thin forward-layout products (K = 192, N in {192, 576, 768}, compact
+// epilogue kinds 1 / 3 / 5 / 6 / 8: ViT-T's qkv / proj / fc1 forward, fc2 / proj data gradients); -1: not covered
+int launch_wreg(GemmParams p, hipStream_t stream);
 }  // namespace sagemm
 using sagemm::GemmParams;
 using sagemm::budget_slots;

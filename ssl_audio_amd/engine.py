@@ -256,7 +256,11 @@ def qv_row_sums(dqkv, d, gq, gv):
     buffers sit 2 d apart in one allocation (train.FlatState's [q | 0 | v] layout), so that one [3 d] vector with the k third skipped
     covers both."""
     fb = lambda: ops.colsum_qv(dqkv, d, gq, gv)
-    if ASUM_FUSE and gv.data_ptr() == gq.data_ptr() + 8 * d and gq.is_contiguous() and gv.is_contiguous() and gq.dtype == torch.float32:
+    # (ONE allocation, not two that happen to lie 2 d apart: separately allocated bias gradients of the per-module path can come out of the
+    # caching allocator exactly that far apart, and a [3 d] view of the first one's 256-byte storage does not exist)
+    same = gq.untyped_storage().data_ptr() == gv.untyped_storage().data_ptr() and \
+        gq.untyped_storage().nbytes() >= (gq.storage_offset() + 3 * d) * 4
+    if ASUM_FUSE and same and gv.data_ptr() == gq.data_ptr() + 8 * d and gq.is_contiguous() and gv.is_contiguous() and gq.dtype == torch.float32:
         return RowSums(gq.view(-1).as_strided((3 * d,), (1,)), d, 2 * d, fb)
     return RowSums(None, 0, 0, fb)
 

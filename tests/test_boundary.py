@@ -268,6 +268,24 @@ def test_custom_ops_cover_every_compute_entry_point():
         torch.ops.ssl_audio.axpy(torch.zeros(4), torch.ones(4), 2.0)
 
 
+def test_qv_bias_gradient_fuses_only_inside_one_allocation():
+    """engine.qv_row_sums: the q / v bias gradient rides along with the qkv weight-gradient launch only when both vectors are the [q | 0 | v]
+    slices of ONE buffer (train.FlatState).  Two separately allocated gradients that merely sit 2 d apart -- the caching allocator hands the
+    per-module path exactly that now and then -- must take the fallback: a [3 d] view of the first one's storage does not exist (a GPU
+    run of tests/test_modules_gpu.py::test_mae_decoder_golden died on it, allocation-order dependent)."""
+    from ssl_audio_amd import engine
+    d = 64
+    base = torch.zeros(3 * d)
+    r = engine.qv_row_sums(None, d, base[:d], base[2 * d:])
+    assert r.out is not None and r.out.shape == (3 * d,) and (r.skip_lo, r.skip_hi) == (d, 2 * d)
+    st = base.untyped_storage()
+    gq = torch.empty(0).set_(st[0:4 * d], 0, (d,), (1,))
+    gv = torch.empty(0).set_(st[8 * d:12 * d], 0, (d,), (1,))
+    assert gv.data_ptr() == gq.data_ptr() + 8 * d                      # as far apart as the flat layout's slices ...
+    assert engine.qv_row_sums(None, d, gq, gv).out is None             # ... but two storages: no fused form
+    assert engine.qv_row_sums(None, d, base[:d], base[2 * d:].clone()).out is None
+
+
 def test_weight_gradient_kernel_selection():
     """engine.stream_wgrad: which weight gradients (models/mae.py:106-129,149-163's Linear layers) take the 192 x 192 streaming split-K
     kernel -- ViT-T's four block shapes and the MAE decoder's wide ones; square d = 384, padded outputs, short reductions and d = 768 do

@@ -277,6 +277,50 @@ def test_gemm_gelu_only_compact_epilogue(dev):
     assert torch.equal(out, out3)
 
 
+def test_gemm_weights_in_registers(dev):
+    """The opt-in weights-in-registers streaming kernel (gemm_wreg.hip, SA_GEMM_WREG: forward layout, K = 192, N in {192, 576, 768}) with each
+    compact epilogue it serves, ragged last stage included -- tests/gemm_wreg_check.py in a subprocess (the library reads the variable
+    once), with SA_GEMM_WREG=2 so that a launch the kernel does not cover fails instead of silently taking the tiled kernels."""
+    import os, subprocess, sys
+    e = dict(os.environ); e["SA_GEMM_WREG"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "gemm_wreg_check.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok wreg" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_gemm_elementwise_at_step_shapes(dev):
+    """Every output ELEMENT of the tiled kernels' compact epilogues at step-sized shapes against an fp64 reference (norm-relative bounds can
+    hide a handful of corrupted elements).  Motivation: a store-data hazard found while building gemm_wreg.hip -- a 16-byte buffer store
+    with an SGPR in its scalar-offset field followed, one instruction later, by a VALU write of a data register stored the NEW value for
+    some lanes; scripts/diag/scan_store_hazard.py finds the same instruction pattern in the tiled kernels' ISA, this test shows it does
+    not bite there (0 elements out of bound)."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    for (M, N, K) in [(63744, 768, 768), (63744, 3072, 768), (127488, 768, 192), (33000 + 77, 768, 3072)]:
+        A = torch.randn(M, K, device=dev, generator=g).to(BF16)
+        W = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(BF16)
+        bias = torch.randn(N, device=dev, generator=g)
+        res = torch.randn(M, N, device=dev, generator=g)
+        aux = torch.randn(M, N, device=dev, generator=g).to(BF16)
+        acc = A.double() @ W.double().t()
+        scale = float(acc.abs().max())
+        for tag, kw, ref, is32 in [("bias->bf16", dict(bias=bias), acc + bias.double(), False),
+                                   ("bias+res->f32", dict(bias=bias, residual=res), acc + bias.double() + res.double(), True),
+                                   ("x aux + colsum", dict(act=4, aux_in=aux), acc * aux.double(), False),
+                                   ("gelu pair", dict(bias=bias, act=3), torch.nn.functional.gelu(acc + bias.double()), False)]:
+            kw = dict(kw)
+            if is32:
+                out = torch.empty(M, N, device=dev); ops.gemm(A, W, out_f32=out, **kw)
+            else:
+                out = torch.empty(M, N, device=dev, dtype=BF16)
+                if tag == "gelu pair": kw["aux_out"] = torch.empty_like(out)
+                if tag.startswith("x aux"): kw["colsum_out"] = torch.zeros(N, device=dev)
+                ops.gemm(A, W, out_bf16=out, **kw)
+            # one rounding of the element (bf16: 2^-8, fp32: 2^-20 relative) + accumulation noise (+ the erf approximation's 2e-3 absolute for GELU)
+            bound = (2.0 ** -20 if is32 else 2.0 ** -8) * ref.abs() + 2e-5 * scale * (K / 768) ** 0.5 + (2e-3 if tag == "gelu pair" else 0.0)
+            nbad = int(((out.double() - ref).abs() > bound).sum())
+            assert nbad == 0, (M, N, K, tag, nbad)
+        del acc, res, aux
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (4000, 2112, 256)])
 def test_gemm_fused_column_sums(dev, M, N, K):
     """colsum_out += column sums of the fp32 epilogue result (fc1's bias gradient taken in the fc2-dgrad epilogue), small
