@@ -273,6 +273,7 @@ def test_qv_bias_gradient_fuses_only_inside_one_allocation():
     slices of ONE buffer (train.FlatState).  Two separately allocated gradients that merely sit 2 d apart -- the caching allocator hands the
     per-module path exactly that now and then -- must take the fallback: a [3 d] view of the first one's storage does not exist (a GPU
     run of tests/test_modules_gpu.py::test_mae_decoder_golden died on it, allocation-order dependent)."""
+    import torch
     from ssl_audio_amd import engine
     d = 64
     base = torch.zeros(3 * d)
