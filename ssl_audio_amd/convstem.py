@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import dist as sdist
 from . import ops
 from .engine import BF16_WEIGHTS, _wgrad, grad_target
+from .functional import pos_table_grad
 
 BF16 = torch.bfloat16
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -114,10 +115,11 @@ def _kpad(ci):
 
 class ConvStemTokensFn(torch.autograd.Function):
     """imgs [S,1,F,T] -> tokens [S, 1 + L (or keep), d] fp32: the conv stem, + positional rows, CLS row, optional keep-gather
-    (prepare_tokens, models/mae.py:349-365 with patch_embed = ConvStem).  Gradients: every stem parameter and the CLS token."""
+    (prepare_tokens, models/mae.py:349-365 with patch_embed = ConvStem).  Gradients: every stem parameter, the CLS token and -- with
+    `--use_learned_pos_embd` (:198-199; `pos_param` = the live nn.Parameter, `pos_A` = its resampling matrix or None) -- the positional table."""
 
     @staticmethod
-    def forward(ctx, imgs, cls_token, pos, ids_keep, stem, *params):
+    def forward(ctx, imgs, cls_token, pos, ids_keep, stem, pos_param, pos_A, *params):
         convs, bns, last = stem.engine_params()
         n = len(convs)
         S, _, F_, T_ = imgs.shape
@@ -154,7 +156,7 @@ class ConvStemTokensFn(torch.autograd.Function):
             raise ValueError(f"ConvStem produced {L} patch tokens but the positional table has {pos.shape[-2] - 1}: the input length must "
                              f"give floor(T / patch) columns through every stride-2 stage (T % {stem.patch_size[1]} == 0)")
         tok = torch.empty(S, 1 + L, d, device=dev)
-        pos2 = pos.reshape(1 + L, d)
+        pos2 = pos.detach().reshape(1 + L, d)
         ops.gemm(a, BF16_WEIGHTS.get(last.weight), bias=last.bias.detach(), residual=pos2[1:], res_mod=L, row_group=L, out_f32=tok.view(S * (1 + L), d))
         ops.fill_cls(tok, S, (1 + L) * d, d, cls_token.detach().reshape(-1), pos2[0])
         ctx.keep_rows = None
@@ -167,6 +169,8 @@ class ConvStemTokensFn(torch.autograd.Function):
             tok = out
         ctx.stem, ctx.saved, ctx.dims, ctx.x, ctx.a_last = stem, saved, dims, x, a
         ctx.cls_param = cls_token
+        ctx.pos_param = pos_param if (pos_param is not None and pos_param.requires_grad) else None
+        ctx.pos_A = pos_A
         ctx.L = L
         ctx.train = stem.training
         return tok
@@ -190,6 +194,7 @@ class ConvStemTokensFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             buf, dcls = grad_target(ctx.cls_param)
             ops.cls_grad(dtok, S, (1 + L) * d, d, buf.view(-1))
+        dpos = pos_table_grad(dtok, ctx.pos_param, ctx.pos_A) if ctx.pos_param is not None else None
         dy16 = ops.cast_bf16(dtok[:, 1:].contiguous().view(S * L, d))
         # 1x1 conv
         dwb, dw_last = grad_target(last.weight)
@@ -239,7 +244,7 @@ class ConvStemTokensFn(torch.autograd.Function):
         out = []
         for l in range(n):
             out += [grads_w[l], grads_g[l], grads_b[l]]
-        return (None, dcls, None, None, None, *out, dw_last, db_last)
+        return (None, dcls, None, None, None, dpos, None, *out, dw_last, db_last)
 
 
 def stem_flat_params(stem):

@@ -15,6 +15,27 @@ BF16, F32 = torch.bfloat16, torch.float32
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 
+def pos_table_grad(full, pos_param, pos_A):
+    """Gradient of the TRAINED positional table (`--use_learned_pos_embd`, models/mae.py:198-199) from the token gradient `full`
+    [S, 1 + L, d] (all token positions; rows dropped by the masking hold zeros): dP = sum over the sequences of dtok at the table's own
+    grid, dP[0] = sum_s dtok[s][0] and dP[1:] = A^T sum_s dtok[s][1:] when the table was resampled by the matrix A (:370-392).  Shared by
+    the patch-projection and the ConvStem token assembly.  Returns what autograd should see (None when accumulated into the flat sink)."""
+    S, n_tok, d = full.shape
+    buf, dpos = grad_target(pos_param)
+    nd = n_tok * d
+    if pos_A is None:
+        ops.cls_grad(full, S, nd, nd, buf.view(-1))          # column sums over the sequences, in a fixed order
+    else:
+        dsum = torch.zeros(n_tok, d, device=full.device)
+        ops.cls_grad(full, S, nd, nd, dsum.view(-1))
+        b2 = buf.view(-1, d)
+        ops.axpy(b2[0], dsum[0])
+        dpatch = torch.empty(pos_A.shape[1], d, device=full.device)
+        ops.matmul_f32(pos_A, dsum[1:], dpatch, trans_a=True)
+        ops.axpy(b2[1:].reshape(-1), dpatch.view(-1))
+    return dpos
+
+
 class TokensFn(torch.autograd.Function):
     """imgs [S,1,F,T] -> tokens [S, 1+L(or keep), d] fp32 (prepare_tokens, models/mae.py:349-365).
     The patch projection is frozen in the reference (models/mae.py:190-192) and so is the sin-cos positional table (:202): the
@@ -59,22 +80,11 @@ class TokensFn(torch.autograd.Function):
             ops.cls_grad(dtok, S, N * d, d, buf.view(-1))
             dcls = ret
         if ctx.pos_param is not None:
-            buf, dpos = grad_target(ctx.pos_param)
             full = dtok
             if ctx.rows is not None:                 # masked: put the kept rows back at their token positions (zeros elsewhere) first
                 full = torch.zeros(ctx.full, device=dtok.device)
                 ops.scatter_add_rows(dtok, N * d, 0, ctx.rows, full, ctx.full[1] * d, 0, S, d)
-            nd = ctx.full[1] * d
-            if ctx.pos_A is None:
-                ops.cls_grad(full, S, nd, nd, buf.view(-1))      # column sums over the sequences, in a fixed order
-            else:                                                # resampled table: dP[0] = sum_s dtok[s][0], dP[1:] = A^T sum_s dtok[s][1:]
-                dsum = torch.zeros(ctx.full[1], d, device=dtok.device)
-                ops.cls_grad(full, S, nd, nd, dsum.view(-1))
-                b2 = buf.view(-1, d)
-                ops.axpy(b2[0], dsum[0])
-                dpatch = torch.empty(ctx.pos_A.shape[1], d, device=dtok.device)
-                ops.matmul_f32(ctx.pos_A, dsum[1:], dpatch, trans_a=True)
-                ops.axpy(b2[1:].reshape(-1), dpatch.view(-1))
+            dpos = pos_table_grad(full, ctx.pos_param, ctx.pos_A)
         return None, dcls, None, None, None, None, dpos, None
 
 

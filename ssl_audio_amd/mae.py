@@ -6,8 +6,8 @@ no submodule's forward is ever called.  Compute is the explicit HIP schedule in 
 The `vitc_*` variants put the ConvStem (convstem.py) in place of the patch projection.
 Options: `norm_pix_loss` (models/mae.py:443-446) and the learned positional table (`--use_learned_pos_embd`, :198-199) are supported -- the
 table with its gradient THROUGH the bicubic resampling to other widths (:370-392: `_learned_pos` returns the interpolation as a matrix A,
-`TokensFn.backward` applies A^T to the summed token gradient; pinned by tests/golden/options.npz) for the plain patch projection; with the
-ConvStem the learned table is refused.  Not provided (out of this path's scope): stochastic depth, forward_attn / forward_viz.
+`TokensFn.backward` / `ConvStemTokensFn.backward` apply A^T to the summed token gradient; pinned by tests/golden/options.npz for the plain
+patch projection and tests/golden/convstem_lpe.npz for the ConvStem).  Not provided (out of this path's scope): stochastic depth, forward_attn / forward_viz.
 """
 from functools import partial
 
@@ -85,8 +85,6 @@ class MaskedAutoencoderViT(nn.Module):
         super().__init__()
         if drop_path_rate:
             raise NotImplementedError("stochastic depth (drop_path_rate > 0) is not on the MI355X hot path (the reference never sets it)")
-        if use_learned_pos_embd and conv_stem:
-            raise NotImplementedError("the learned positional embedding is implemented for the plain patch projection (not the ConvStem)")
         if in_chans != 1:
             raise NotImplementedError("audio spectrogram input only (in_chans=1)")
         if (embed_dim // num_heads) != 64 or (use_decoder and decoder_embed_dim // decoder_num_heads != 64):
@@ -236,7 +234,8 @@ class MaskedAutoencoderViT(nn.Module):
         else:
             ids_keep, mask, ids_restore = self.masking_indices(B, L, mask_ratio, x.device, noise)
         if self.conv_stem:
-            tok = ConvStemTokensFn.apply(x, self.cls_token, pos, ids_keep, self.patch_embed, *stem_flat_params(self.patch_embed))
+            tok = ConvStemTokensFn.apply(x, self.cls_token, pos, ids_keep, self.patch_embed,
+                                         self.pos_embed if self.use_learned_pos_embd else None, pos_A, *stem_flat_params(self.patch_embed))
         else:
             tok = Fn.TokensFn.apply(x, self.cls_token, self.patch_embed.proj.weight, self.patch_embed.proj.bias, pos, ids_keep,
                                     self.pos_embed if self.use_learned_pos_embd else None, pos_A)

@@ -575,6 +575,36 @@ def gen_convstem():
     save("convstem", **out)
 
 
+def gen_convstem_lpe():
+    """ConvStem ViTC WITH `--use_learned_pos_embd` (models/mae.py:186-199): the trained table is resampled by the reference's bicubic map for every
+    non-square input (:367-392 -- also at the table's own grid, 64 x 96) and its gradient flows back through that map.  Micro encoder in
+    train mode, T = 96 (same grid, resampled) and T = 208 (13 columns out of 6): latent, table / CLS / last-conv gradients."""
+    out = {}
+    for tag, T_ in [("t96", 96), ("t208", 208)]:
+        torch.manual_seed(31)
+        m = ref_mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                         norm_layer=partial(nn.LayerNorm, eps=1e-6), conv_stem=True, use_learned_pos_embd=True)
+        perturb_(m, 32)
+        with torch.no_grad():
+            m.pos_embed.add_(0.05 * torch.randn(m.pos_embed.shape))
+        assert m.pos_embed.requires_grad
+        m.train()
+        if tag == "t96":                                        # (the same seeds give both cases the same weights: stored once)
+            for k, v in m.state_dict().items():
+                out["sd." + k] = t2n(v)
+        torch.manual_seed(33)
+        x = torch.randn(3, 1, 64, T_)
+        lat = m(x)
+        w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+        m.zero_grad()
+        (lat * w).sum().backward()
+        out.update({f"{tag}_x": t2n(x), f"{tag}_latent": t2n(lat), f"{tag}_dpos": t2n(m.pos_embed.grad), f"{tag}_dcls": t2n(m.cls_token.grad)})
+        last = [n for n, _ in m.named_parameters() if n.startswith("patch_embed.proj.") and n.endswith(".weight")][-1]
+        out[f"{tag}_dlast"] = t2n(dict(m.named_parameters())[last].grad)
+        out[f"{tag}_last_name"] = np.array(last)
+    save("convstem_lpe", **out)
+
+
 def gen_audiontt():
     """AudioNTT2022 (model.py:130-191) in train mode: BatchNorm2d on batch statistics, Dropout(0.3) with its mask recovered from a
     forward hook (input / output of the Dropout module), small MLP widths so the fixture stays small (n_mels 64, d 1280, hidden 256)."""
@@ -857,6 +887,7 @@ if __name__ == "__main__":
     gen_hear() if "hear" in sys.argv[1:] else None
     gen_resnet() if "resnet" in sys.argv[1:] else None
     gen_convstem() if "convstem" in sys.argv[1:] else None
+    gen_convstem_lpe() if "convstem_lpe" in sys.argv[1:] else None
     gen_audiontt() if "audiontt" in sys.argv[1:] else None
     gen_bn_eval() if "bn_eval" in sys.argv[1:] else None
     gen_schedule() if "schedule" in sys.argv[1:] else None

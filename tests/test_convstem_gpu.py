@@ -162,6 +162,44 @@ def test_convstem_vit_golden(dev, golden, tag):
             np.testing.assert_allclose(after[name].cpu().numpy(), g[k], rtol=2e-2, atol=2e-3, err_msg=name)
 
 
+@pytest.mark.parametrize("tag,T_", [("t96", 96), ("t208", 208)])
+def test_convstem_learned_pos_golden(dev, golden, tag, T_):
+    """ConvStem ViTC with `--use_learned_pos_embd` (refused until round 5): latent 2e-2 against the reference, the trained table's gradient
+    THROUGH the bicubic resampling (A^T applied to the summed token gradient: ConvStemTokensFn.backward -> functional.pos_table_grad) and
+    the CLS gradient 5e-2 -- the bounds of the patch-projection case (test_options_projector_depth_learned_pos_norm_pix_golden) --,
+    the stem's last convolution 5e-2; and under a fixed mask the table gradient equals the oracle's on the same mask."""
+    from oracle import vit as ovit
+    g = golden("convstem_lpe")
+    m = mae.MaskedAutoencoderViT(img_size=(64, 96), patch_size=[16, 16], in_chans=1, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4,
+                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), conv_stem=True, use_learned_pos_embd=True).to(dev)
+    sd = {k[3:]: T(v, dev, torch.long if "num_batches" in k else torch.float32) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    assert m.pos_embed.requires_grad
+    x = T(g[f"{tag}_x"], dev)
+    lat = m(x)
+    assert rel(lat, g[f"{tag}_latent"]) < 2e-2
+    w = torch.linspace(-1, 1, lat.numel(), device=dev).reshape(lat.shape)
+    m.zero_grad()
+    (lat * w).sum().backward()
+    last = str(g[f"{tag}_last_name"])
+    errs = {"dpos": rel(m.pos_embed.grad, g[f"{tag}_dpos"]), "dcls": rel(m.cls_token.grad, g[f"{tag}_dcls"]),
+            "dlast": rel(dict(m.named_parameters())[last].grad, g[f"{tag}_dlast"])}
+    print(tag, errs)
+    assert max(errs.values()) < 5e-2, errs
+    # a fixed mask: only kept positions (and the CLS slot) feed the table's gradient
+    L = 4 * (T_ // 16)
+    mask = torch.zeros(3, L)
+    mask[:, 1::2] = 1.0
+    m.load_state_dict(sd, strict=True)
+    m.zero_grad()
+    w2 = torch.linspace(-1, 1, 3 * 128, device=dev).reshape(3, 128)
+    (m(x, mask_ratio=mask.to(dev)) * w2).sum().backward()
+    p = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    p["pos_embed"].requires_grad_(True)
+    (ovit.forward(x.cpu(), p, 2, (4, 6), mask=mask, patch=(16, 16), learned_pos=True) * w2.cpu()).sum().backward()
+    assert rel(m.pos_embed.grad, p["pos_embed"].grad) < 5e-2
+
+
 def test_convstem_eval_mode_golden(dev, golden):
     """`m.eval()` (what hear/sample/vit.py does before embedding): the stem's BatchNorm2d layers normalise with their RUNNING statistics,
     as nn.BatchNorm2d does -- tokens / latent against the reference's eval forward (tests/golden/bn_eval.npz), buffers untouched, a clip's

@@ -408,6 +408,27 @@ def test_convstem_oracle_golden(golden, tag):
         np.testing.assert_allclose(rv.numpy(), g[f"{tag}_after.patch_embed.proj.{3 * l + 1}.running_var"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag,T_", [("t96", 96), ("t208", 208)])
+def test_convstem_learned_pos_oracle_golden(golden, tag, T_):
+    """ConvStem ViTC with `--use_learned_pos_embd` (models/mae.py:186-199, :367-392): the oracle's latent and the gradients of the trained
+    positional table (through the bicubic resampling: 64 x 96 is not square, so even the table's own grid is resampled), the CLS token and
+    the stem's last convolution against the reference's (tests/golden/convstem_lpe.npz), fp32."""
+    from oracle import vit as ovit
+    g = golden("convstem_lpe")
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in g.items() if k.startswith("sd.")}
+    last = str(g[tag + "_last_name"])
+    names = ["pos_embed", "cls_token", last]
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    x = torch.from_numpy(np.array(g[tag + "_x"]))
+    lat = ovit.forward(x, leaf, 2, (4, 6), patch=(16, 16), learned_pos=True)
+    assert float((lat.detach() - torch.from_numpy(np.array(g[tag + "_latent"]))).abs().max()) < 3e-5
+    w = torch.linspace(-1, 1, lat.numel()).reshape(lat.shape)
+    gs = dict(zip(names, torch.autograd.grad((lat * w).sum(), [leaf[k] for k in names])))
+    for k, key in (("pos_embed", "_dpos"), ("cls_token", "_dcls"), (last, "_dlast")):
+        ref = torch.from_numpy(np.array(g[tag + key]))
+        assert float((gs[k] - ref).norm() / (ref.norm() + 1e-30)) < 1e-4, k
+
+
 def test_hear_frame_audio_matches_the_reference_loop():
     """ssl_audio_amd.hear.utils.frame_audio (vectorised) == the literal restatement of hear/utils.py:56-106 (oracle/hear.py)."""
     from oracle import hear as ohear
