@@ -300,8 +300,21 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
     // (the host checks that the output spans less than 4 GiB, as it does for the operands)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(dst, (uint32_t)((((int64_t)p.M - 1) * ld + p.N) * 2));
     const uint32_t ld2 = (uint32_t)ld * 2u;
-    const uint32_t voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)ch * 16u;
+    // The row block's offset travels in the PER-LANE offset (one v_add per store), not in the instruction's scalar-offset field: a 16-byte
+    // buffer store with a register in that field reads its data registers late, hipcc leaves one wait state before a VALU write of them,
+    // and on gfx950 that was measurably not enough (gemm_wreg.hip's first build stored a later value for lanes 12 - 15: DESIGN.md section 6,
+    // round 5, item 11).  These stores were never caught doing it (tests/test_kernels_gpu.py::test_gemm_elementwise_at_step_shapes), but the
+    // ISA had the pattern at 94 sites (scripts/diag/scan_store_hazard.py); without a register in the field the hazard does not exist.
+    // -DSA_STORE_SOFF=1 brings the scalar-offset form back (A/B builds).
+#ifndef SA_STORE_SOFF
+#define SA_STORE_SOFF 0
+#endif
+    uint32_t voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)ch * 16u;
     uint32_t soff = (uint32_t)m_base * ld2 + (uint32_t)n_base * 2u;
+#if !SA_STORE_SOFF
+    voff += soff;
+    soff = 0;
+#endif
     const bool nt = p.nt_store != 0;
 #pragma unroll
     for (int it = 0; it < 2 * NI; ++it) {
@@ -310,9 +323,15 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
                           : *reinterpret_cast<const uint4*>(wlds + r * EPI_STRIDE + ch * 16);
       const u32x4 val = {q.x, q.y, q.z, q.w};
       // streaming stores: a tile round writes 4 MiB per XCD, i.e. the whole L2, and would evict the operand panels
+#if SA_STORE_SOFF
       if (nt) __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, 2);
       else __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, 0);
       soff += 8u * ld2;
+#else
+      if (nt) __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, 0, 0);
+      voff += 8u * ld2;
+#endif
     }
     return;
   }
