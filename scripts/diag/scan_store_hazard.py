@@ -1,10 +1,17 @@
 """Scan gfx950 ISA listings for the store-data pattern that corrupted outputs in gemm_wreg.hip:
-a buffer/global store of MORE than 8 bytes whose scalar-offset field holds an SGPR, followed within WINDOW vector instructions by a VALU
-write of one of its data registers.  hipcc leaves one wait state there; on gfx950 the store read the new value for some lanes.
-   hipcc ... -save-temps=obj -c x.hip -o /tmp/isa/x.o ; python scripts/diag/scan_store_hazard.py /tmp/isa/*gfx950.s"""
+a buffer store of MORE than 8 bytes whose scalar-offset field holds an SGPR, followed within WINDOW vector instructions by a VALU write
+of one of its data registers.  hipcc pads such a sequence to two wait states only when the field holds NO register (with an SGPR it
+assumes the hardware needs none); on gfx950 a store with an SGPR there and one instruction in between read the new value for some lanes.
+--flat also lists global / flat stores of more than 8 bytes (those ARE covered by the compiler's rule: expect sites whose distance is
+made up of scalar instructions / branches, informational only).
+   hipcc ... -save-temps=obj -c x.hip -o /tmp/isa/x.o ; python scripts/diag/scan_store_hazard.py [--flat] /tmp/isa/*gfx950.s"""
 import re, sys
 WINDOW = 3
 st = re.compile(r"^\s*buffer_store_dword(x3|x4)\s+v\[(\d+):(\d+)\],\s*(?:v\d+|off),\s*s\[\d+:\d+\],\s*(s\d+|m0|\S+)")
+# global / flat stores of more than 8 bytes: hipcc's rule applies to them whatever their address form (argv flag --flat lists them too)
+gst = re.compile(r"^\s*(?:global|flat|scratch)_store_dword(x3|x4)\s+(?:v\[\d+:\d+\]|v\d+),\s*v\[(\d+):(\d+)\]")
+FLAT = "--flat" in sys.argv
+if FLAT: sys.argv.remove("--flat")
 vdst = re.compile(r"^\s*(v_[a-z0-9_]+)\s+(v\[(\d+):(\d+)\]|v(\d+))")
 total = 0
 for path in sys.argv[1:]:
@@ -13,7 +20,10 @@ for path in sys.argv[1:]:
     for i, ln in enumerate(lines):
         if ln.endswith(":") and ln.startswith("_Z"): kern = ln[:60]
         m = st.match(ln)
-        if not m or not m.group(4).startswith("s"): continue
+        if m and not m.group(4).startswith("s"): m = None
+        if m is None and FLAT:
+            m = gst.match(ln)
+        if not m: continue
         lo, hi = int(m.group(2)), int(m.group(3))
         seen = 0
         for j in range(i + 1, min(i + 40, len(lines))):

@@ -300,11 +300,12 @@ __device__ __forceinline__ void staged_store_bf16(const GemmParams& p, f32x4 (&v
     // (the host checks that the output spans less than 4 GiB, as it does for the operands)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(dst, (uint32_t)((((int64_t)p.M - 1) * ld + p.N) * 2));
     const uint32_t ld2 = (uint32_t)ld * 2u;
-    // The row block's offset travels in the PER-LANE offset (one v_add per store), not in the instruction's scalar-offset field: a 16-byte
-    // buffer store with a register in that field reads its data registers late, hipcc leaves one wait state before a VALU write of them,
-    // and on gfx950 that was measurably not enough (gemm_wreg.hip's first build stored a later value for lanes 12 - 15: DESIGN.md section 6,
-    // round 5, item 11).  These stores were never caught doing it (tests/test_kernels_gpu.py::test_gemm_elementwise_at_step_shapes), but the
-    // ISA had the pattern at 94 sites (scripts/diag/scan_store_hazard.py); without a register in the field the hazard does not exist.
+    // The row block's offset travels in the PER-LANE offset (one v_add per store), not in the instruction's scalar-offset field: hipcc keeps
+    // two wait states between a 16-byte store and a VALU write of its data registers only when that field holds NO register -- with an
+    // SGPR there it assumes the hardware needs none, and on gfx950 that measurably did not hold (gemm_wreg.hip's first build stored a
+    // later value for lanes 12 - 15: DESIGN.md section 6, round 5, item 11).  These stores were never caught doing it
+    // (tests/test_kernels_gpu.py::test_gemm_elementwise_at_step_shapes), but the ISA had the unprotected pattern at 94 sites
+    // (scripts/diag/scan_store_hazard.py); in this form the compiler's own rule pads them.
     // -DSA_STORE_SOFF=1 brings the scalar-offset form back (A/B builds).
 #ifndef SA_STORE_SOFF
 #define SA_STORE_SOFF 0

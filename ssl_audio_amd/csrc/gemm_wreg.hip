@@ -149,12 +149,12 @@ __global__ __launch_bounds__(64 * (NB == 2 ? 8 : NB)) void gemm_wreg_kernel(cons
   constexpr int NIN = KIND == 3 ? 6 : (KIND == 5 ? 3 : 1);
   u32x4 in_cur[NIN], in_next[NIN];
   // Every offset is per-lane offset + a COMPILE-TIME constant (the instruction's immediate field), never an SGPR:
-  //  * a 16-byte buffer store with a register in its scalar-offset field reads its data registers late, and hipcc leaves ONE wait state
-  //    between such a store and a VALU write of those registers (its "store of more than 8 bytes" rule).  On gfx950 that was not
-  //    enough here: with the column block's offset in an SGPR, `buffer_store_dwordx4 v[166:169], .., s9 offen` followed by
+  //  * hipcc keeps two wait states between a store of more than 8 bytes and a VALU write of its data registers -- but only when the store's
+  //    scalar-offset field holds no register; with an SGPR there it assumes the hardware needs none and pads nothing.  On gfx950 that
+  //    did not hold: with the column block's offset in an SGPR, `buffer_store_dwordx4 v[166:169], .., s9 offen` followed by
   //    `v_pk_mul ..; v_and_b32 v167, ..` stored the NEW v167 for lanes 12 - 15 of every row -- dword 1 of the lanes whose data is read
   //    last (kind 5: 1.2 % of the outputs wrong while the column sums of the same values were right).  Without a register in that
-  //    field the rule's hazard does not exist.
+  //    field the compiler's own rule applies (`store; v_pk_mul; s_nop 0; v_and`).
   //  * rows past M -- of the last stage, and of stages past the end that are requested ahead -- fall out of the resource's range.
   auto load_inputs = [&](int rowbase, u32x4 (&in)[NIN]) {
     if constexpr (KIND == 3) {

@@ -290,8 +290,8 @@ def test_gemm_weights_in_registers(dev):
 def test_gemm_elementwise_at_step_shapes(dev):
     """Every output ELEMENT of the tiled kernels' compact epilogues at step-sized shapes against an fp64 reference (norm-relative bounds can
     hide a handful of corrupted elements).  Motivation: a store-data hazard found while building gemm_wreg.hip -- a 16-byte buffer store
-    with an SGPR in its scalar-offset field followed, one instruction later, by a VALU write of a data register stored the NEW value for
-    some lanes; scripts/diag/scan_store_hazard.py found the same instruction pattern in the tiled kernels' ISA (one source site, since
+    with an SGPR in its scalar-offset field (which hipcc does not pad) followed, one instruction later, by a VALU write of a data
+    register stored the NEW value for some lanes; scripts/diag/scan_store_hazard.py found the same instruction pattern in the tiled kernels' ISA (one source site, since
     rewritten to per-lane offsets); this test showed it never bit there (0 elements out of bound before and after) and stays as the guard."""
     g = torch.Generator(device=dev).manual_seed(0)
     for (M, N, K) in [(63744, 768, 768), (63744, 3072, 768), (127488, 768, 192), (33000 + 77, 768, 3072)]:
