@@ -24,8 +24,6 @@ def copy():
     k = nxt(); bufs[k].copy_(bufs[(k + 3) % 6])
 def expand():
     k = nxt(); bufs[k].view(M, 4, 192).copy_(x192[k].view(M, 1, 192).expand(M, 4, 192))
-def expand_mul():
-    k = nxt(); torch.mul(x192[k].view(M, 1, 192), 2.0, out=None)
 for name, fn, nbytes in [("fill 196 MB bf16", fill, M * 768 * 2), ("copy 196 -> 196 MB", copy, 2 * M * 768 * 2), ("expand 49 -> 196 MB (1 : 4)", expand, M * 960 * 2)]:
     us = timeit(fn)
     print(f"{name:32s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s")
