@@ -319,6 +319,21 @@ def test_gemm_elementwise_at_step_shapes(dev):
             nbad = int(((out.double() - ref).abs() > bound).sum())
             assert nbad == 0, (M, N, K, tag, nbad)
         del acc, res, aux
+    # the ring kernel (k-strided weight: the data-gradient layout without a transposed copy) shares the bf16 row stores: plain and x GELU'(aux)
+    M, N, K = 63744, 768, 3072
+    A = torch.randn(M, K, device=dev, generator=g).to(BF16)
+    W = (torch.randn(K, N, device=dev, generator=g) * 0.05).to(BF16)
+    pre = torch.randn(M, N, device=dev, generator=g).to(BF16)
+    acc = A.double() @ W.double()
+    scale = float(acc.abs().max())
+    hh = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(hh).sum().backward()
+    for tag, kw, ref in [("NN ->bf16", dict(), acc), ("NN x GELU'(aux)", dict(act=2, aux_in=pre), acc * hh.grad)]:
+        out = torch.empty(M, N, device=dev, dtype=BF16)
+        ops.gemm(A, W, b_kmajor=False, out_bf16=out, **kw)
+        bound = 2.0 ** -8 * ref.abs() + 2e-5 * scale * (K / 768) ** 0.5
+        nbad = int(((out.double() - ref).abs() > bound).sum())
+        assert nbad == 0, (tag, nbad)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (4000, 2112, 256)])
